@@ -1,0 +1,238 @@
+"""ctypes binding of include/cudabrot_amd.h -- one Python name per C entry point, nothing more.
+
+Names follow the reference's own (cudabrot.cu): FractalDimensions (:46-58), IterationControl (:62-67),
+InitializeRNG (:146-149) -> initialize_rng, DrawBuddhabrot (:379-414) -> draw_buddhabrot,
+RecomputePixelDeltas (:505-527), SetGrayscalePixels (:454-468), SaveImage (:548-577); Renderer is
+SetupCUDA + RenderImage (:153-189, :471-501) as an object.
+
+There is no fallback path: the shared library must exist (``make`` or ``__graft_entry__.build()``) or
+this module raises at import, and every device call raises :class:`CudabrotError` on a HIP error.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+CB_DEFAULT_THREADS = 512 * 512  # cudabrot.cu:20,23
+CB_SAMPLES_PER_THREAD = 50  # cudabrot.cu:34
+CB_DEFAULT_RNG_SEED = 1337  # cudabrot.cu:37
+CB_KERNEL_DEFAULT = 0
+CB_KERNEL_SIMPLE = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.path.join(_HERE, "libcudabrot_amd.so")
+
+
+class CudabrotError(RuntimeError):
+    """A C-ABI call returned a nonzero hipError_t."""
+
+    def __init__(self, code, what):
+        self.code = int(code)
+        super().__init__("%s failed: HIP error %d (%s)" % (what, self.code, _error_string(self.code)))
+
+
+class FractalDimensions(C.Structure):
+    """cb_fractal_dimensions == FractalDimensions (cudabrot.cu:46-58)."""
+
+    _fields_ = [
+        ("w", C.c_int),
+        ("h", C.c_int),
+        ("min_real", C.c_double),
+        ("min_imag", C.c_double),
+        ("max_real", C.c_double),
+        ("max_imag", C.c_double),
+        ("delta_real", C.c_double),
+        ("delta_imag", C.c_double),
+    ]
+
+    @classmethod
+    def make(cls, w, h, min_real=-2.0, max_real=2.0, min_imag=-2.0, max_imag=2.0):
+        d = cls(w, h, min_real, min_imag, max_real, max_imag, 0.0, 0.0)
+        ok, msg = recompute_pixel_deltas(d)
+        if not ok:
+            raise ValueError(msg)
+        return d
+
+
+class IterationControl(C.Structure):
+    """cb_iteration_control == IterationControl (cudabrot.cu:62-67)."""
+
+    _fields_ = [("max_escape_iterations", C.c_int), ("min_escape_iterations", C.c_int)]
+
+
+class Counters(C.Structure):
+    """cb_counters: exact device-side workload counters."""
+
+    _fields_ = [
+        (n, C.c_uint64)
+        for n in (
+            "samples",
+            "rejected",
+            "never_escaped",
+            "too_fast",
+            "recorded",
+            "iterate_steps",
+            "replay_steps",
+            "increments",
+            "probe_steps",
+            "status",
+        )
+    ]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "cudabrot_amd: %s is missing -- build it with `make` (or __graft_entry__.build()); "
+            "there is no CPU fallback" % path
+        )
+    lib_ = C.CDLL(path)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    dims_p, it_p, cnt_p = C.POINTER(FractalDimensions), C.POINTER(IterationControl), C.POINTER(Counters)
+    sigs = {
+        "cb_abi_version": (i32, []),
+        "cb_error_string": (C.c_char_p, [i32]),
+        "cb_recompute_pixel_deltas": (i32, [dims_p, C.POINTER(C.c_char_p)]),
+        "cb_rng_state_bytes": (C.c_size_t, [u32]),
+        "cb_initialize_rng": (i32, [u64, u64, u32, vp, vp]),
+        "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp]),
+        "cb_renderer_create": (i32, [C.POINTER(vp), i32, dims_p, it_p, u64, u64, u32]),
+        "cb_renderer_render_passes": (i32, [vp, u32, i32]),
+        "cb_renderer_read_histogram": (i32, [vp, vp]),
+        "cb_renderer_write_histogram": (i32, [vp, vp]),
+        "cb_renderer_read_counters": (i32, [vp, cnt_p]),
+        "cb_renderer_device_histogram": (vp, [vp]),
+        "cb_renderer_destroy": (None, [vp]),
+        "cb_set_grayscale_pixels": (None, [vp, i32, i32, C.c_double, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
+        "cb_save_image": (i32, [C.c_char_p, vp, i32, i32]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib_, name)  # AttributeError here = the library does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    return lib_
+
+
+lib = _load()
+EXPORTED_SYMBOLS = (
+    "cb_abi_version cb_error_string cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
+    "cb_draw_buddhabrot cb_renderer_create cb_renderer_render_passes cb_renderer_read_histogram "
+    "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
+    "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image"
+).split()
+
+
+def _error_string(code):
+    return lib.cb_error_string(int(code)).decode()
+
+
+def _check(code, what):
+    if code != 0:
+        raise CudabrotError(code, what)
+
+
+def recompute_pixel_deltas(dims):
+    """RecomputePixelDeltas (cudabrot.cu:505-527) -> (ok, message-or-None); fills dims.delta_*."""
+    msg = C.c_char_p()
+    ok = lib.cb_recompute_pixel_deltas(C.byref(dims), C.byref(msg))
+    return bool(ok), (None if ok else msg.value.decode())
+
+
+def rng_state_bytes(n_threads):
+    return int(lib.cb_rng_state_bytes(n_threads))
+
+
+def initialize_rng(seed, first_subsequence, n_threads, d_states, stream=0):
+    """InitializeRNG (cudabrot.cu:146-149,179) on caller-owned device memory (integer pointers)."""
+    _check(lib.cb_initialize_rng(seed, first_subsequence, n_threads, d_states, stream), "cb_initialize_rng")
+
+
+def draw_buddhabrot(dims, d_hist, iterations, d_states, n_threads, samples_per_thread, d_counters=0,
+                    kernel_variant=CB_KERNEL_DEFAULT, stream=0):
+    """DrawBuddhabrot (cudabrot.cu:379-414,485-486) on caller-owned device memory; asynchronous."""
+    _check(
+        lib.cb_draw_buddhabrot(C.byref(dims), d_hist, C.byref(iterations), d_states, n_threads,
+                               samples_per_thread, d_counters, kernel_variant, stream),
+        "cb_draw_buddhabrot",
+    )
+
+
+class Renderer:
+    """SetupCUDA + RenderImage (cudabrot.cu:153-189, 471-501) over the C ABI's cb_renderer."""
+
+    def __init__(self, dims, iterations, device=0, seed=CB_DEFAULT_RNG_SEED, first_subsequence=0,
+                 n_threads=CB_DEFAULT_THREADS):
+        self.dims = dims
+        self.iterations = iterations
+        self.n_threads = n_threads
+        self._h = C.c_void_p()
+        _check(
+            lib.cb_renderer_create(C.byref(self._h), device, C.byref(dims), C.byref(iterations), seed,
+                                   first_subsequence, n_threads),
+            "cb_renderer_create",
+        )
+
+    def render_passes(self, passes, kernel_variant=CB_KERNEL_DEFAULT):
+        _check(lib.cb_renderer_render_passes(self._h, passes, kernel_variant), "cb_renderer_render_passes")
+
+    def read_histogram(self):
+        out = np.empty(self.dims.w * self.dims.h, dtype=np.uint64)
+        _check(lib.cb_renderer_read_histogram(self._h, out.ctypes.data), "cb_renderer_read_histogram")
+        return out.reshape(self.dims.h, self.dims.w)
+
+    def write_histogram(self, hist):
+        a = np.ascontiguousarray(hist, dtype=np.uint64).reshape(-1)
+        if a.size != self.dims.w * self.dims.h:
+            raise ValueError("histogram size does not match the canvas")
+        _check(lib.cb_renderer_write_histogram(self._h, a.ctypes.data), "cb_renderer_write_histogram")
+
+    def read_counters(self):
+        c = Counters()
+        _check(lib.cb_renderer_read_counters(self._h, C.byref(c)), "cb_renderer_read_counters")
+        return c
+
+    @property
+    def device_histogram(self):
+        return lib.cb_renderer_device_histogram(self._h)
+
+    def close(self):
+        if self._h:
+            lib.cb_renderer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def set_grayscale_pixels(hist, gamma):
+    """SetGrayscalePixels (cudabrot.cu:454-468) -> (u16 image [h,w] host-endian, max count, scale)."""
+    a = np.ascontiguousarray(hist, dtype=np.uint64)
+    h, w = a.shape
+    gray = np.empty((h, w), dtype=np.uint16)
+    mx, scale = C.c_uint64(), C.c_double()
+    lib.cb_set_grayscale_pixels(a.ctypes.data, w, h, float(gamma), gray.ctypes.data, C.byref(mx), C.byref(scale))
+    return gray, int(mx.value), float(scale.value)
+
+
+def save_image(path, gray):
+    """SaveImage (cudabrot.cu:548-577); ``gray`` is copied (the C call byte-swaps in place)."""
+    g = np.array(gray, dtype=np.uint16, order="C")
+    h, w = g.shape
+    return int(lib.cb_save_image(os.fsencode(path), g.ctypes.data, w, h))

@@ -1,0 +1,247 @@
+// capi.hip -- implementation of include/cudabrot_amd.h (the C ABI).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+#define CB_TRY(expr)                       \
+  do {                                     \
+    hipError_t cb_e_ = (expr);             \
+    if (cb_e_ != hipSuccess) return (int) cb_e_; \
+  } while (0)
+
+// One copy of the jump matrices per device, created on first use and kept for the process lifetime.
+std::mutex g_matrix_mutex;
+const uint32_t *g_matrices[64] = {nullptr};
+
+int device_matrices(const uint32_t **out) {
+  int dev = 0;
+  CB_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return (int) hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(g_matrix_mutex);
+  if (!g_matrices[dev]) {
+    std::vector<uint32_t> host((size_t) cb::kSeqJumpMatrices * cb::kMatrixWords);
+    cb::build_sequence_jump_matrices(host.data());
+    uint32_t *d = nullptr;
+    CB_TRY(hipMalloc(&d, host.size() * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void) hipFree(d);
+      return (int) e;
+    }
+    g_matrices[dev] = d;
+  }
+  *out = g_matrices[dev];
+  return 0;
+}
+
+// x / delta == x * (1 / delta) bit for bit iff delta is a (normal) power of two.
+bool exact_reciprocal(double delta, double *inv) {
+  int e = 0;
+  if (!(delta > 0.0) || !isfinite(delta)) return false;
+  if (frexp(delta, &e) != 0.5) return false;
+  const double r = 1.0 / delta;
+  if (!isfinite(r) || r == 0.0 || fpclassify(delta) != FP_NORMAL || fpclassify(r) != FP_NORMAL) {
+    return false;
+  }
+  *inv = r;
+  return true;
+}
+
+cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_control *it,
+                       cb_pixel *d_hist, void *d_states, uint32_t n_threads,
+                       uint32_t samples_per_thread, cb_counters *d_counters) {
+  cb::DrawArgs a;
+  memset(&a, 0, sizeof(a));
+  a.min_real = dims->min_real;
+  a.min_imag = dims->min_imag;
+  a.delta_real = dims->delta_real;
+  a.delta_imag = dims->delta_imag;
+  a.inv_delta_real = 0.0;
+  a.inv_delta_imag = 0.0;
+  a.pow2_real = exact_reciprocal(dims->delta_real, &a.inv_delta_real) ? 1 : 0;
+  a.pow2_imag = exact_reciprocal(dims->delta_imag, &a.inv_delta_imag) ? 1 : 0;
+  a.w = dims->w;
+  a.h = dims->h;
+  a.max_iter = it->max_escape_iterations;
+  a.min_iter = it->min_escape_iterations;
+  a.head_steps = cb::choose_head_steps(a.max_iter, a.min_iter);
+  a.n_threads = n_threads;
+  a.samples_per_thread = samples_per_thread;
+  a.hist = reinterpret_cast<unsigned long long *>(d_hist);
+  a.states = reinterpret_cast<uint32_t *>(d_states);
+  a.counters = d_counters;
+  return a;
+}
+
+}  // namespace
+
+struct cb_renderer {
+  int device;
+  cb_fractal_dimensions dims;
+  cb_iteration_control iterations;
+  uint32_t n_threads;
+  cb_pixel *d_hist;
+  uint32_t *d_states;
+  cb_counters *d_counters;
+  hipStream_t stream;
+};
+
+extern "C" {
+
+int cb_abi_version(void) { return CB_ABI_VERSION; }
+
+const char *cb_error_string(int code) {
+  if (code == 0) return "no error";
+  return hipGetErrorString((hipError_t) code);
+}
+
+int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg) {
+  const char *m = nullptr;
+  if (dims->w <= 0) {
+    m = "Output width must be positive.";
+  } else if (dims->h <= 0) {
+    m = "Output height must be positive.";
+  } else if (dims->max_real <= dims->min_real) {
+    m = "Maximum real value must be greater than minimum real value.";
+  } else if (dims->max_imag <= dims->min_imag) {
+    // (sic) the reference's wording, cudabrot.cu:520-521
+    m = "Minimum imaginary value must be greater than maximum imaginary value.";
+  }
+  if (m) {
+    if (msg) *msg = m;
+    return 0;
+  }
+  dims->delta_imag = (dims->max_imag - dims->min_imag) / ((double) dims->h);
+  dims->delta_real = (dims->max_real - dims->min_real) / ((double) dims->w);
+  return 1;
+}
+
+size_t cb_rng_state_bytes(uint32_t n_threads) { return (size_t) n_threads * 6u * sizeof(uint32_t); }
+
+int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
+                      void *stream) {
+  if (n_threads == 0) return 0;
+  if (!d_states) return (int) hipErrorInvalidValue;
+  const uint32_t *mats = nullptr;
+  int rc = device_matrices(&mats);
+  if (rc) return rc;
+  return (int) cb::launch_rng_init(seed, first_subsequence, n_threads,
+                                   reinterpret_cast<uint32_t *>(d_states), mats,
+                                   reinterpret_cast<hipStream_t>(stream));
+}
+
+int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
+                       const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
+                       uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
+                       void *stream) {
+  if (!dims || !iterations || !d_hist || !d_states) return (int) hipErrorInvalidValue;
+  if (dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
+  const cb::DrawArgs a =
+      make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread, d_counters);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  switch (kernel_variant) {
+    case CB_KERNEL_DEFAULT:
+      return (int) cb::launch_draw_wave(a, s);
+    case CB_KERNEL_SIMPLE:
+      return (int) cb::launch_draw_simple(a, s);
+    default:
+      return (int) hipErrorInvalidValue;
+  }
+}
+
+int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
+                       const cb_iteration_control *iterations, uint64_t seed,
+                       uint64_t first_subsequence, uint32_t n_threads) {
+  if (!out || !dims || !iterations || dims->w <= 0 || dims->h <= 0 || n_threads == 0) {
+    return (int) hipErrorInvalidValue;
+  }
+  *out = nullptr;
+  CB_TRY(hipSetDevice(device));  // cudabrot.cu:155
+  cb_renderer *r = new (std::nothrow) cb_renderer;
+  if (!r) return (int) hipErrorOutOfMemory;
+  memset(r, 0, sizeof(*r));
+  r->device = device;
+  r->dims = *dims;
+  r->iterations = *iterations;
+  r->n_threads = n_threads;
+  const size_t hist_bytes = (size_t) dims->w * (size_t) dims->h * sizeof(cb_pixel);
+  hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&r->d_hist, hist_bytes);                  // cudabrot.cu:168
+  if (e == hipSuccess) e = hipMemsetAsync(r->d_hist, 0, hist_bytes, r->stream);  // cudabrot.cu:169
+  if (e == hipSuccess) e = hipMalloc(&r->d_states, cb_rng_state_bytes(n_threads));  // :177
+  if (e == hipSuccess) e = hipMalloc(&r->d_counters, sizeof(cb_counters));
+  if (e == hipSuccess) e = hipMemsetAsync(r->d_counters, 0, sizeof(cb_counters), r->stream);
+  int rc = (int) e;
+  if (!rc) rc = cb_initialize_rng(seed, first_subsequence, n_threads, r->d_states, r->stream);
+  if (!rc) rc = (int) hipStreamSynchronize(r->stream);  // cudabrot.cu:181
+  if (rc) {
+    cb_renderer_destroy(r);
+    return rc;
+  }
+  *out = r;
+  return 0;
+}
+
+int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant) {
+  if (!r) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  // 50 samples per thread per reference pass (cudabrot.cu:34,390); keep each launch below 2^31.
+  const uint32_t max_passes_per_launch = 0x7fffffffu / CB_SAMPLES_PER_THREAD;
+  while (passes > 0) {
+    const uint32_t now = passes < max_passes_per_launch ? passes : max_passes_per_launch;
+    int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
+                                now * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
+                                r->stream);
+    if (rc) return rc;
+    passes -= now;
+  }
+  return (int) hipStreamSynchronize(r->stream);  // cudabrot.cu:487
+}
+
+int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out) {
+  if (!r || !host_out) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
+  CB_TRY(hipMemcpyAsync(host_out, r->d_hist, bytes, hipMemcpyDeviceToHost, r->stream));
+  return (int) hipStreamSynchronize(r->stream);
+}
+
+int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in) {
+  if (!r || !host_in) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
+  CB_TRY(hipMemcpyAsync(r->d_hist, host_in, bytes, hipMemcpyHostToDevice, r->stream));
+  return (int) hipStreamSynchronize(r->stream);
+}
+
+int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out) {
+  if (!r || !host_out) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  CB_TRY(hipMemcpyAsync(host_out, r->d_counters, sizeof(cb_counters), hipMemcpyDeviceToHost,
+                        r->stream));
+  return (int) hipStreamSynchronize(r->stream);
+}
+
+cb_pixel *cb_renderer_device_histogram(cb_renderer *r) { return r ? r->d_hist : nullptr; }
+
+void cb_renderer_destroy(cb_renderer *r) {
+  if (!r) return;
+  (void) hipSetDevice(r->device);
+  if (r->stream) (void) hipStreamSynchronize(r->stream);
+  (void) hipFree(r->d_hist);
+  (void) hipFree(r->d_states);
+  (void) hipFree(r->d_counters);
+  if (r->stream) (void) hipStreamDestroy(r->stream);
+  delete r;
+}
+
+}  // extern "C"

@@ -1,0 +1,449 @@
+// cli_main.cpp -- `cudabrot`: command-line drop-in for the reference binary.
+//
+// The process boundary IS the reference's public interface: argv in, stdout text,
+// exit code, a 16-bit PGM and the raw -s buffer out.  This file reproduces that contract
+// (cudabrot.cu:579-791: flags :662-754, messages, usage -> exit 0, errors on stdout -> exit 1) on top of
+// the C ABI in include/cudabrot_amd.h.  Rendering is done by the hand-written gfx950 kernels only: there
+// is no CPU fallback, without a usable GPU the program prints the reference's error line and exits 1.
+//
+// Observable differences, all deliberate:
+//  * the -s buffer holds 64-bit counters (w*h*8 bytes); a reference-format file (w*h*4 bytes, uint32)
+//    is accepted on load and widened;
+//  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
+//    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
+//  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
+//    --stats.
+#include <errno.h>
+#include <signal.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/cudabrot_amd.h"
+
+namespace {
+
+volatile sig_atomic_t g_quit_requested = 0;
+
+struct Settings {
+  int device = 0;                                   // -d
+  const char *output_image = "output.pgm";          // -o   (cudabrot.cu:26,764)
+  const char *inprogress_file = nullptr;            // -s
+  double seconds_to_run = 10.0;                     // -t   (cudabrot.cu:769)
+  double gamma_correction = 1.0;                    // -g   (cudabrot.cu:770)
+  cb_iteration_control iterations = {100, 20};      // -m -c (cudabrot.cu:765-766)
+  cb_fractal_dimensions canvas = {1000, 1000, -2.0, -2.0, 2.0, 2.0, 0.0, 0.0};  // cudabrot.cu:533-538
+  long fixed_passes = -1;                           // --passes (extension; <0: run by the clock)
+  int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
+  bool print_stats = false;                         // --stats  (extension)
+};
+
+// The usage text is the command's documented interface (cudabrot.cu:579-620) and is printed as is.
+const char kUsageBody[] =
+    "Options may be one or more of the following:\n"
+    "  --help: Prints these instructions.\n"
+    "  -d <device number>: Sets which GPU to use. Defaults to GPU 0.\n"
+    "  -o <output file name>: If provided, the rendered image will be saved\n"
+    "     to a .pgm file with the given name. Otherwise, saves the image\n"
+    "     to output.pgm.\n"
+    "  -m <max escape iterations>: The maximum number of iterations to use\n"
+    "     before giving up on seeing whether a point escapes.\n"
+    "  -c <min escape iterations>: If a point escapes before this number of\n"
+    "     iterations, it will be ignored.\n"
+    "  -g <gamma correction>: A gamma-correction value to use on the\n"
+    "     resulting image. If negative, no gamma correction will occur.\n"
+    "  -t <seconds to run>: A number of seconds to run the calculation for.\n"
+    "     Defaults to 10.0. If negative, the program will run continuously\n"
+    "     and will terminate (saving the image) when it receives a SIGINT.\n"
+    "  -w <width>: The width of the output image, in pixels. Defaults to\n"
+    "     1000.\n"
+    "  -h <height>: The height of the output image, in pixels. Defaults to\n"
+    "     1000.\n"
+    "  -s <save/load file>: If provided, this gives a file name into which\n"
+    "     the rendering buffer will be saved, for future continuation.\n"
+    "     If the program is loaded and the file exists, the buffer will be\n"
+    "     filled with the contents of the file, but the dimensions must\n"
+    "     match. Note that this file may be huge for high-resolution images.\n"
+    "\n"
+    "The following settings control the location of the output image on the\n"
+    "complex plane, but samples are always drawn from the entire Mandelbrot-\n"
+    "set domain (-2-2i to 2+2i). So these settings can be used to save\n"
+    "memory or \"crop\" the output, but won't otherwise speed up rendering:\n"
+    "  --min-real <min real>: The minimum value along the real axis to\n"
+    "             include in the output image. Defaults to -2.0.\n"
+    "  --max-real <max real>: The maximum value along the real axis to\n"
+    "             include in the output image. Defaults to 2.0.\n"
+    "  --min-imag <min imag>: The minimum value along the imaginary axis to\n"
+    "             include in the output image. Defaults to -2.0.\n"
+    "  --max-imag <max imag>: The maximum value along the imaginary axis to\n"
+    "             include in the output image. Defaults to 2.0.\n";
+
+// Usage always ends the process with status 0, also after a bad argument (cudabrot.cu:619).
+[[noreturn]] void usage_and_exit(const char *program) {
+  printf("Usage: %s [options]\n\n", program);
+  fputs(kUsageBody, stdout);
+  exit(0);
+}
+
+// ---- argument table ----------------------------------------------------------------------------
+
+enum class Value { kNone, kInt, kDouble, kText };
+
+struct Flag {
+  const char *name;
+  Value value;
+  const char *missing_value_message;  // nullptr: "Argument %s needs a value."
+  bool revalidates_canvas;            // -w -h --min/max-*: canvas re-checked at once (:704-749)
+  std::function<void(Settings &, long, double, const char *)> store;
+};
+
+const std::vector<Flag> &flag_table() {
+  static const std::vector<Flag> table = {
+      {"-d", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) { s.device = (int) i; }},
+      {"-o", Value::kText, "Missing output file name.", false,
+       [](Settings &s, long, double, const char *t) { s.output_image = t; }},
+      {"-s", Value::kText, "Missing in-progress buffer file name.", false,
+       [](Settings &s, long, double, const char *t) { s.inprogress_file = t; }},
+      {"-m", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) {
+         s.iterations.max_escape_iterations = (int) i;
+         if (s.iterations.max_escape_iterations > 60000) {  // cudabrot.cu:692-695
+           printf("Warning: Using a high number of iterations may cause the "
+                  "program respond slowly to Ctrl+C or time running out.\n");
+         }
+       }},
+      {"-c", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) {
+         s.iterations.min_escape_iterations = (int) i;
+       }},
+      {"-w", Value::kInt, nullptr, true,
+       [](Settings &s, long i, double, const char *) { s.canvas.w = (int) i; }},
+      {"-h", Value::kInt, nullptr, true,
+       [](Settings &s, long i, double, const char *) { s.canvas.h = (int) i; }},
+      {"-g", Value::kDouble, nullptr, false,
+       [](Settings &s, long, double d, const char *) { s.gamma_correction = d; }},
+      {"-t", Value::kDouble, nullptr, false,
+       [](Settings &s, long, double d, const char *) { s.seconds_to_run = d; }},
+      {"--min-real", Value::kDouble, nullptr, true,
+       [](Settings &s, long, double d, const char *) { s.canvas.min_real = d; }},
+      {"--max-real", Value::kDouble, nullptr, true,
+       [](Settings &s, long, double d, const char *) { s.canvas.max_real = d; }},
+      {"--min-imag", Value::kDouble, nullptr, true,
+       [](Settings &s, long, double d, const char *) { s.canvas.min_imag = d; }},
+      {"--max-imag", Value::kDouble, nullptr, true,
+       [](Settings &s, long, double d, const char *) { s.canvas.max_imag = d; }},
+      // extensions
+      {"--passes", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) { s.fixed_passes = i < 0 ? 0 : i; }},
+      {"--kernel", Value::kText, nullptr, false,
+       [](Settings &s, long, double, const char *t) {
+         s.kernel_variant = (strcmp(t, "simple") == 0) ? CB_KERNEL_SIMPLE : CB_KERNEL_DEFAULT;
+       }},
+      {"--stats", Value::kNone, nullptr, false,
+       [](Settings &s, long, double, const char *) { s.print_stats = true; }},
+  };
+  return table;
+}
+
+// Canvas validation with the reference's messages (cudabrot.cu:505-527).
+bool canvas_ok(Settings &s) {
+  const char *why = nullptr;
+  if (cb_recompute_pixel_deltas(&s.canvas, &why)) return true;
+  printf("%s\n", why);
+  return false;
+}
+
+Settings parse_arguments(int argc, char **argv) {
+  Settings s;
+  if (!canvas_ok(s)) {  // cudabrot.cu:539-542
+    printf("Internal error setting default canvas boundaries!\n");
+    exit(1);
+  }
+  for (int i = 1; i < argc; i++) {
+    const char *arg = argv[i];
+    if (strcmp(arg, "--help") == 0) usage_and_exit(argv[0]);
+    const Flag *flag = nullptr;
+    for (const Flag &f : flag_table()) {
+      if (strcmp(arg, f.name) == 0) {
+        flag = &f;
+        break;
+      }
+    }
+    if (!flag) {
+      printf("Invalid argument: %s\n", arg);  // cudabrot.cu:751
+      usage_and_exit(argv[0]);
+    }
+    long as_int = 0;
+    double as_double = 0.0;
+    const char *text = nullptr;
+    if (flag->value != Value::kNone) {
+      if (i + 1 >= argc) {
+        if (flag->missing_value_message) {
+          printf("%s\n", flag->missing_value_message);
+        } else {
+          printf("Argument %s needs a value.\n", arg);  // cudabrot.cu:629,648
+        }
+        usage_and_exit(argv[0]);
+      }
+      text = argv[++i];
+      if (flag->value != Value::kText) {
+        // whole-string numbers only; an empty string is not a number (cudabrot.cu:632-639,651-656)
+        char *end = nullptr;
+        if (flag->value == Value::kInt) {
+          as_int = (int) strtol(text, &end, 10);  // truncated to int like the reference
+        } else {
+          as_double = strtod(text, &end);
+        }
+        if (*end != 0 || text[0] == 0) {
+          printf("Invalid number given to argument %s: %s\n", arg, text);
+          usage_and_exit(argv[0]);
+        }
+      }
+    }
+    flag->store(s, as_int, as_double, text);
+    if (flag->revalidates_canvas && !canvas_ok(s)) usage_and_exit(argv[0]);
+  }
+  return s;
+}
+
+// ---- the run -------------------------------------------------------------------------------------
+
+double wall_seconds() {  // cudabrot.cu:122-129
+  struct timespec ts;
+  if (clock_gettime(CLOCK_REALTIME, &ts) != 0) {
+    printf("Error getting time.\n");
+    exit(1);
+  }
+  return (double) ts.tv_sec + (double) ts.tv_nsec / 1e9;
+}
+
+class Run {
+ public:
+  explicit Run(const Settings &s) : cfg_(s) {}
+  ~Run() { release(); }
+
+  int execute() {
+    printf("Creating %dx%d image, %d max iterations.\n", cfg_.canvas.w, cfg_.canvas.h,
+           cfg_.iterations.max_escape_iterations);  // cudabrot.cu:779-780
+    printf("Calculating image...\n");
+    setup();
+    load_inprogress();
+    render();
+    save_inprogress();
+    printf("Saving image.\n");
+    save_image();
+    printf("Done! Output image saved: %s\n", cfg_.output_image);
+    release();
+    return 0;
+  }
+
+ private:
+  Settings cfg_;
+  cb_renderer *renderer_ = nullptr;
+  cb_pixel *counts_ = nullptr;   // host mirror of the histogram
+  uint16_t *gray_ = nullptr;
+
+  uint64_t pixel_count() const { return (uint64_t) cfg_.canvas.w * (uint64_t) cfg_.canvas.h; }
+  uint64_t buffer_bytes() const { return pixel_count() * sizeof(cb_pixel); }
+
+  void release() {  // cudabrot.cu:112-119
+    cb_renderer_destroy(renderer_);
+    renderer_ = nullptr;
+    free(gray_);
+    gray_ = nullptr;
+    free(counts_);
+    counts_ = nullptr;
+  }
+
+  [[noreturn]] void die() {
+    release();
+    exit(1);
+  }
+
+  // The reference's device-error line (cudabrot.cu:134-141), wording kept: scripts may match on it.
+  void check(int rc, const char *what, int line) {
+    if (rc == 0) return;
+    printf("CUDA error %d (%s) in %s, line %d (%s)\n", rc, cb_error_string(rc), __FILE__, line,
+           what);
+    die();
+  }
+#define CB_CHECK(call) check((call), #call, __LINE__)
+
+  void setup() {  // cudabrot.cu:153-189
+    float gpu_mib = (float) (buffer_bytes() + cb_rng_state_bytes(CB_DEFAULT_THREADS));
+    gpu_mib /= (1024.0 * 1024.0);
+    float cpu_mib = (float) (buffer_bytes() + pixel_count() * sizeof(uint16_t));
+    cpu_mib /= (1024.0 * 1024.0);
+    printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
+    CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
+                                CB_DEFAULT_RNG_SEED, 0, CB_DEFAULT_THREADS));
+    counts_ = (cb_pixel *) calloc(1, buffer_bytes());
+    if (!counts_) die();
+    gray_ = (uint16_t *) calloc(pixel_count(), sizeof(uint16_t));
+    if (!gray_) {
+      printf("Failed allocating grayscale image.\n");
+      die();
+    }
+  }
+
+  void load_inprogress() {  // cudabrot.cu:215-258
+    const char *path = cfg_.inprogress_file;
+    if (!path) return;
+    FILE *f = fopen(path, "rb");
+    printf("Loading previous image state from %s.\n", path);
+    if (!f) {
+      if (errno == ENOENT) {
+        printf("File %s doesn't exist yet. Not loading.\n", path);
+        return;
+      }
+      printf("Failed opening %s: %s\n", path, strerror(errno));
+      die();
+    }
+    // size check, cudabrot.cu:192-211,236-245
+    long size = -1;
+    if (fseek(f, 0, SEEK_END) != 0) {
+      printf("Failed seeking file end: %s\n", strerror(errno));
+      die();
+    }
+    if ((size = ftell(f)) < 0) {
+      printf("Failed reading file size: %s\n", strerror(errno));
+      die();
+    }
+    if (fseek(f, 0, SEEK_SET) != 0) {
+      printf("Failed seeking file start: %s\n", strerror(errno));
+      die();
+    }
+    const uint64_t narrow_bytes = pixel_count() * sizeof(uint32_t);
+    bool ok;
+    if ((uint64_t) size == narrow_bytes) {
+      // written by the reference: uint32 counters, widened here
+      std::vector<uint32_t> narrow(pixel_count());
+      ok = fread(narrow.data(), narrow_bytes, 1, f) == 1;
+      for (uint64_t i = 0; ok && i < pixel_count(); i++) counts_[i] = narrow[i];
+    } else if ((uint64_t) size == buffer_bytes()) {
+      ok = fread(counts_, buffer_bytes(), 1, f) == 1;
+    } else {
+      printf("The size of %s doesn't match the expected size of %lu bytes.\n", path,
+             (unsigned long) buffer_bytes());
+      fclose(f);
+      die();
+    }
+    if (!ok) {
+      printf("Failed reading %s: %s\n", path, strerror(errno));
+      fclose(f);
+      die();
+    }
+    fclose(f);
+    CB_CHECK(cb_renderer_write_histogram(renderer_, counts_));
+  }
+
+  void save_inprogress() {  // cudabrot.cu:262-280
+    const char *path = cfg_.inprogress_file;
+    if (!path) return;
+    printf("Saving in-progress buffer to %s.\n", path);
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+      printf("Failed opening %s: %s\n", path, strerror(errno));
+      die();
+    }
+    if (fwrite(counts_, buffer_bytes(), 1, f) != 1) {
+      printf("Failed writing data to %s: %s\n", path, strerror(errno));
+      fclose(f);
+      die();
+    }
+    fclose(f);
+  }
+
+  // The pass loop (cudabrot.cu:471-501).  Launch length follows the measured pass time so that the
+  // clock and the quit flag are looked at about every 0.2 s.
+  void render() {
+    printf("Calculating Buddhabrot.\n");
+    const bool by_clock = cfg_.fixed_passes < 0;
+    if (by_clock) {
+      if (cfg_.seconds_to_run < 0) {
+        printf("Press ctrl+C to finish.\n");
+      } else {
+        printf("Running for %.03f seconds.\n", cfg_.seconds_to_run);
+      }
+    }
+    fflush(stdout);
+    const double launch_seconds = 0.2;
+    const double t0 = wall_seconds();
+    long done = 0, next = 1;
+    while (!g_quit_requested) {
+      if (!by_clock) {
+        if (done >= cfg_.fixed_passes) break;
+        next = cfg_.fixed_passes - done;
+        if (next > 256) next = 256;
+      }
+      CB_CHECK(cb_renderer_render_passes(renderer_, (uint32_t) next, cfg_.kernel_variant));
+      done += next;
+      if (!by_clock) continue;
+      const double elapsed = wall_seconds() - t0;
+      if (cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run) break;
+      double budget = launch_seconds;
+      if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < budget) {
+        budget = cfg_.seconds_to_run - elapsed;
+      }
+      const double per_pass = elapsed / (double) done;
+      next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
+      if (next < 1) next = 1;
+      if (next > 4096) next = 4096;
+    }
+    CB_CHECK(cb_renderer_read_histogram(renderer_, counts_));
+    printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
+    if (cfg_.print_stats) print_stats();
+    uint64_t max = 0;
+    double scale = 0.0;
+    cb_set_grayscale_pixels(counts_, cfg_.canvas.w, cfg_.canvas.h, cfg_.gamma_correction, gray_,
+                            &max, &scale);
+    printf("Max value: %lu, scale: %f\n", (unsigned long) max, scale);  // cudabrot.cu:437
+  }
+
+  void print_stats() {
+    cb_counters c;
+    CB_CHECK(cb_renderer_read_counters(renderer_, &c));
+    fprintf(stderr,
+            "{\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
+            "\"recorded\": %llu, \"iterate_steps\": %llu, \"replay_steps\": %llu, "
+            "\"increments\": %llu, \"probe_steps\": %llu, \"status\": %llu}\n",
+            (unsigned long long) c.samples, (unsigned long long) c.rejected,
+            (unsigned long long) c.never_escaped, (unsigned long long) c.too_fast,
+            (unsigned long long) c.recorded, (unsigned long long) c.iterate_steps,
+            (unsigned long long) c.replay_steps, (unsigned long long) c.increments,
+            (unsigned long long) c.probe_steps, (unsigned long long) c.status);
+  }
+
+  void save_image() {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0
+    static const char *const kWhy[] = {nullptr, "Failed opening output image.",
+                                       "Failed writing pgm header.", "Failed writing pixel data."};
+    const int rc = cb_save_image(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h);
+    if (rc >= 1 && rc <= 3) printf("%s\n", kWhy[rc]);
+  }
+#undef CB_CHECK
+};
+
+}  // namespace
+
+// cudabrot.cu:756-760
+extern "C" void on_sigint(int signal_number) {
+  g_quit_requested = 1;
+  printf("Signal %d received, waiting for current pass to finish...\n", signal_number);
+}
+
+int main(int argc, char **argv) {
+  const Settings settings = parse_arguments(argc, argv);
+  if (signal(SIGINT, on_sigint) == SIG_ERR) {  // cudabrot.cu:774-778
+    printf("Failed setting signal handler.\n");
+    return 1;
+  }
+  Run run(settings);
+  return run.execute();
+}

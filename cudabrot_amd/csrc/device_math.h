@@ -1,0 +1,120 @@
+// device_math.h -- the canonical arithmetic of the hot path, shared by every kernel.
+//
+// Bit-exactness contract: this file is compiled with
+// -ffp-contract=off; every fused operation is an explicit __builtin_fma; iterate and replay use the
+// SAME mandel_step, so a replayed orbit retraces the tested orbit bit for bit (the hazard the
+// reference warns of at cudabrot.cu:342-346).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cb {
+
+// XORWOW generator state (rocRAND 4.2 rocrand_xorwow.h:72-89, the live part): 160 xorshift bits and
+// the Weyl value.  Kept in registers for the whole launch; the reference reloads it from global
+// memory for every sample (cudabrot.cu:382,392-393).
+struct Xorwow {
+  uint32_t x0, x1, x2, x3, x4, d;
+};
+
+// rocrand(&state): rocrand_xorwow.h:165-177.
+__device__ __forceinline__ uint32_t xorwow_next(Xorwow &s) {
+  const uint32_t t = s.x0 ^ (s.x0 >> 2);
+  s.x0 = s.x1;
+  s.x1 = s.x2;
+  s.x2 = s.x3;
+  s.x3 = s.x4;
+  s.x4 = (s.x4 ^ (s.x4 << 4)) ^ (t ^ (t << 1));
+  s.d += 362437u;
+  return s.d + s.x4;
+}
+
+// One coordinate of a starting point: curand_uniform_double(rng) * 4.0 - 2.0 (cudabrot.cu:392-393)
+// with rocRAND's mapping U = 2^-53 + v * 2^-53, v = x1 | ((x2 >> 11) << 32)
+// (rocrand_uniform.h:102-109).  U = (v + 1) * 2^-53 and U*4 - 2 = (v + 1 - 2^52) * 2^-51 are both
+// exactly representable, so every formulation that is exact in each step gives the same bits; this
+// one needs two conversions and two FMAs (hi*2^32 + lo < 2^53 is exact; 2^-51 - 2 is representable
+// and the final sum is exact).
+__device__ __forceinline__ double sample_coordinate(Xorwow &s) {
+  const uint32_t v1 = xorwow_next(s);
+  const uint32_t v2 = xorwow_next(s);
+  const double lo = (double) v1;
+  const double hi = (double) (v2 >> 11);
+  const double v = __builtin_fma(hi, 4294967296.0, lo);
+  return __builtin_fma(v, 0x1p-51, 0x1p-51 - 2.0);
+}
+
+// InMainCardioid, cudabrot.cu:284-290 (q*q + imag_squared is one FMA in the canonical sequence).
+__device__ __forceinline__ bool in_main_cardioid(double real, double imag) {
+  const double imag_squared = imag * imag;
+  double q = real - 0.25;
+  q = __builtin_fma(q, q, imag_squared);
+  return (q * (q + (real - 0.25))) < (imag_squared * 0.25);
+}
+
+// InOrder2Bulb, cudabrot.cu:294-298 (tmp + imag*imag is one FMA in the canonical sequence).
+__device__ __forceinline__ bool in_order2_bulb(double real, double imag) {
+  double tmp = real + 1.0;
+  tmp = tmp * tmp;
+  return __builtin_fma(imag, imag, tmp) < (1.0 / 16.0);
+}
+
+// One z <- z^2 + c step (cudabrot.cu:331-333 and :357-359); returns |z|^2 as tested at :336/:363.
+//   ii = i*i; t = fma(r,r,-ii); nr = cr + t; ni = fma(r+r, i, ci); m = fma(ni,ni, nr*nr)
+// 7 fp64 instructions (3 FMA, 2 MUL, 2 ADD) = the 10 algorithmic flops of SURVEY.md section 8(d).
+__device__ __forceinline__ double mandel_step(double cr, double ci, double &r, double &i) {
+  const double ii = i * i;
+  const double t = __builtin_fma(r, r, -ii);
+  const double nr = cr + t;
+  const double ni = __builtin_fma(r + r, i, ci);
+  r = nr;
+  i = ni;
+  return __builtin_fma(ni, ni, nr * nr);
+}
+
+// Canvas geometry as the kernels consume it: FractalDimensions (cudabrot.cu:46-58) plus the exact
+// reciprocal fast path of SURVEY.md H3.
+struct Canvas {
+  double min_real, min_imag;
+  double delta_real, delta_imag;
+  double inv_delta_real, inv_delta_imag;  // valid iff pow2_real / pow2_imag
+  int w, h;
+  int pow2_real, pow2_imag;  // delta is a power of two: x / delta == x * (1/delta) bit for bit
+};
+
+// IncrementPixelCounter, cudabrot.cu:302-314, with the += made a device-scope atomic (the
+// reference's plain += loses updates under races) and 64-bit indexing.  Returns
+// true if a counter was incremented.
+__device__ __forceinline__ bool increment_pixel_counter(double real, double imag,
+                                                        unsigned long long *data, const Canvas &c) {
+  if ((real < c.min_real) || (imag < c.min_imag)) return false;
+  const double fx = real - c.min_real;
+  const double fy = imag - c.min_imag;
+  // (int) of a double: v_cvt_i32_f64 saturates where x86 yields INT_MIN; both fail the bounds test.
+  const int col = c.pow2_real ? (int) (fx * c.inv_delta_real) : (int) (fx / c.delta_real);
+  const int row = c.pow2_imag ? (int) (fy * c.inv_delta_imag) : (int) (fy / c.delta_imag);
+  if ((row >= 0) && (row < c.h) && (col >= 0) && (col < c.w)) {
+    unsigned long long *p = data + ((unsigned long long) row * (unsigned long long) c.w +
+                                    (unsigned long long) col);
+    // result unused -> no-return global_atomic_add_x2, agent scope
+    __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
+
+// Lane index inside the wave and prefix population count of a 64-bit lane mask.
+__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
+__device__ __forceinline__ int mask_prefix(unsigned long long mask) {
+  return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace cb

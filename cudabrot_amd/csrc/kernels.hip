@@ -1,0 +1,547 @@
+// kernels.hip -- hand-written gfx950 device code for the Buddhabrot hot path.
+//
+// Compiled with -ffp-contract=off (see device_math.h).  wave = 64 lanes everywhere.
+//
+// Kernels
+//   rng_init_kernel    InitializeRNG (cudabrot.cu:146-149): one XORWOW state per thread, jump-ahead
+//                      by subsequence * 2^67 through GF(2) matrices held in device memory.
+//   draw_simple_kernel DrawBuddhabrot (cudabrot.cu:379-414) one lane = one reference thread, in
+//                      lock-step.  Validation baseline: ~2 % lane efficiency at deep max_iter
+//                      (SURVEY.md H2).
+//   draw_wave_kernel   the product path: every wave schedules three stages over its own 64
+//                      generator subsequences and two wave-private LDS queues (see the long comment
+//                      in front of it).
+#include "kernels.h"
+
+#include "device_math.h"
+
+namespace cb {
+
+// ------------------------------------------------------------------------------------------------
+// RNG init
+// ------------------------------------------------------------------------------------------------
+
+struct SeedState {
+  uint32_t x[5];
+  uint32_t d;
+};
+
+// x <- M x over GF(2); M in rocRAND's image layout m[(word*32+bit)*5 + k] (rocrand_xorwow.h:49-66).
+// The matrix address is wave-uniform, so its rows arrive through scalar loads.
+__device__ __forceinline__ void gf2_mat_vec(const uint32_t *__restrict__ m, uint32_t x[5]) {
+  uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+#pragma unroll 1
+  for (int wd = 0; wd < 5; ++wd) {
+    const uint32_t xv = x[wd];
+#pragma unroll 4
+    for (int j = 0; j < 32; ++j) {
+      const uint32_t *row = m + (wd * 32 + j) * 5;
+      const uint32_t sel = 0u - ((xv >> j) & 1u);
+      r0 ^= sel & row[0];
+      r1 ^= sel & row[1];
+      r2 ^= sel & row[2];
+      r3 ^= sel & row[3];
+      r4 ^= sel & row[4];
+    }
+  }
+  x[0] = r0;
+  x[1] = r1;
+  x[2] = r2;
+  x[3] = r3;
+  x[4] = r4;
+}
+
+__global__ void __launch_bounds__(256)
+rng_init_kernel(SeedState seed, unsigned long long first_subsequence, uint32_t n_threads,
+                uint32_t *__restrict__ states, const uint32_t *__restrict__ matrices) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = tid < n_threads;
+  const unsigned long long subseq = first_subsequence + (valid ? tid : 0u);
+  uint32_t x[5] = {seed.x[0], seed.x[1], seed.x[2], seed.x[3], seed.x[4]};
+  // discard_subsequence (rocrand_xorwow.h:149-158): x <- A^(subseq * 2^67) x, d unchanged.
+  // Binary digits instead of rocRAND's base-4 digits: one matrix product per set bit.
+  for (int b = 0; b < kSeqJumpMatrices; ++b) {
+    const bool bit = valid && ((subseq >> b) & 1ull);
+    if (__ballot(bit) == 0ull) {
+      if (__ballot(valid && (subseq >> b) != 0ull) == 0ull) break;  // no lane has higher bits
+      continue;
+    }
+    if (bit) gf2_mat_vec(matrices + (size_t) b * kMatrixWords, x);
+  }
+  if (valid) {
+    states[0 * (size_t) n_threads + tid] = x[0];
+    states[1 * (size_t) n_threads + tid] = x[1];
+    states[2 * (size_t) n_threads + tid] = x[2];
+    states[3 * (size_t) n_threads + tid] = x[3];
+    states[4 * (size_t) n_threads + tid] = x[4];
+    states[5 * (size_t) n_threads + tid] = seed.d;
+  }
+}
+
+hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads,
+                           uint32_t *d_states, const uint32_t *d_matrices, hipStream_t stream) {
+  if (n_threads == 0) return hipSuccess;
+  SeedState s;
+  seed_state(seed, s.x, &s.d);
+  const uint32_t blocks = (n_threads + 255u) / 256u;
+  hipLaunchKernelGGL(rng_init_kernel, dim3(blocks), dim3(256), 0, stream, s,
+                     (unsigned long long) first_subsequence, n_threads, d_states, d_matrices);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Shared pieces of the draw kernels
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ Canvas make_canvas(const DrawArgs &a) {
+  Canvas c;
+  c.min_real = a.min_real;
+  c.min_imag = a.min_imag;
+  c.delta_real = a.delta_real;
+  c.delta_imag = a.delta_imag;
+  c.inv_delta_real = a.inv_delta_real;
+  c.inv_delta_imag = a.inv_delta_imag;
+  c.w = a.w;
+  c.h = a.h;
+  c.pow2_real = a.pow2_real;
+  c.pow2_imag = a.pow2_imag;
+  return c;
+}
+
+__device__ __forceinline__ Xorwow load_rng(const uint32_t *states, uint32_t n, uint32_t tid) {
+  Xorwow s;
+  s.x0 = states[0 * (size_t) n + tid];
+  s.x1 = states[1 * (size_t) n + tid];
+  s.x2 = states[2 * (size_t) n + tid];
+  s.x3 = states[3 * (size_t) n + tid];
+  s.x4 = states[4 * (size_t) n + tid];
+  s.d = states[5 * (size_t) n + tid];
+  return s;
+}
+
+__device__ __forceinline__ void store_rng(uint32_t *states, uint32_t n, uint32_t tid,
+                                          const Xorwow &s) {
+  states[0 * (size_t) n + tid] = s.x0;
+  states[1 * (size_t) n + tid] = s.x1;
+  states[2 * (size_t) n + tid] = s.x2;
+  states[3 * (size_t) n + tid] = s.x3;
+  states[4 * (size_t) n + tid] = s.x4;
+  states[5 * (size_t) n + tid] = s.d;
+}
+
+// Per-lane statistics, summed over the wave at kernel end (one atomic per counter per wave).
+struct LaneStats {
+  unsigned long long samples = 0, rejected = 0, never_escaped = 0, too_fast = 0, recorded = 0,
+                     iterate_steps = 0, replay_steps = 0, increments = 0, probe_steps = 0,
+                     status = 0;
+};
+
+__device__ __forceinline__ void flush_stats(cb_counters *counters, const LaneStats &s) {
+  if (!counters) return;
+  const unsigned long long v[10] = {
+      wave_sum(s.samples),       wave_sum(s.rejected),     wave_sum(s.never_escaped),
+      wave_sum(s.too_fast),      wave_sum(s.recorded),     wave_sum(s.iterate_steps),
+      wave_sum(s.replay_steps),  wave_sum(s.increments),   wave_sum(s.probe_steps),
+      wave_sum(s.status)};
+  if (lane_id() == 0) {
+    unsigned long long *c = reinterpret_cast<unsigned long long *>(counters);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      if (v[i]) __hip_atomic_fetch_add(c + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (v[9]) __hip_atomic_fetch_or(c + 9, v[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// draw_simple_kernel: the reference's loop structure, one lane per reference thread
+// ------------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) draw_simple_kernel(DrawArgs a) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = tid < a.n_threads;
+  const Canvas cv = make_canvas(a);
+  LaneStats st;
+  if (valid) {
+    Xorwow rng = load_rng(a.states, a.n_threads, tid);
+    for (uint32_t sample = 0; sample < a.samples_per_thread; ++sample) {  // cudabrot.cu:390
+      const double real = sample_coordinate(rng);
+      const double imag = sample_coordinate(rng);
+      st.samples++;
+      if (in_main_cardioid(real, imag) || in_order2_bulb(real, imag)) {  // cudabrot.cu:398
+        st.rejected++;
+        continue;
+      }
+      // IterateMandelbrot, cudabrot.cu:319-340
+      double r = real, i = imag;
+      int k = a.max_iter;
+      for (int it = 0; it < a.max_iter; ++it) {
+        if (mandel_step(real, imag, r, i) > 4.0) {
+          k = it;
+          break;
+        }
+      }
+      if (k >= a.max_iter) {  // cudabrot.cu:407
+        st.never_escaped++;
+        st.iterate_steps += (unsigned long long) (a.max_iter > 0 ? a.max_iter : 0);
+        continue;
+      }
+      st.iterate_steps += (unsigned long long) k + 1ull;
+      if (k < a.min_iter) {  // cudabrot.cu:408
+        st.too_fast++;
+        continue;
+      }
+      st.recorded++;
+      // IterateAndRecord, cudabrot.cu:347-365; bounded so that a wave always terminates
+      r = real;
+      i = imag;
+      for (int it = 0; it <= a.max_iter; ++it) {
+        const double m = mandel_step(real, imag, r, i);
+        st.replay_steps++;
+        st.increments += increment_pixel_counter(r, i, a.hist, cv) ? 1ull : 0ull;
+        if (m > 4.0) break;
+        if (it == a.max_iter) st.status |= CB_STATUS_REPLAY_RUNAWAY;
+      }
+    }
+    store_rng(a.states, a.n_threads, tid, rng);
+  }
+  flush_stats(a.counters, st);
+}
+
+hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream) {
+  if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
+  const uint32_t blocks = (a.n_threads + 255u) / 256u;
+  hipLaunchKernelGGL(draw_simple_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// draw_wave_kernel: the product path
+// ------------------------------------------------------------------------------------------------
+//
+// Why: at max_iter = 20000 a sample needs 168 iterations on average but 89 % of samples need < 20
+// and 0.8 % need all 20000; one lane per reference thread in lock-step keeps ~2 % of the lanes busy
+// (SURVEY.md H2).  Histogram increments commute, so ANY schedule of the fixed multiset of samples
+// {(subsequence t, sample n)} gives the identical histogram, provided each subsequence is consumed
+// in order with exactly four draws per sample.  Each wave therefore owns 64 subsequences (lane l of
+// wave v is reference thread 64 v + l, exactly like the reference) and runs three stages over them,
+// decoupled by two wave-private queues in LDS (no barriers: a wave's LDS operations are in order):
+//
+//   HEAD    all 64 lanes draw a starting point (4 XORWOW outputs, registers only), apply the
+//           cardioid / bulb test and run the first head_steps iterations under a lane mask.
+//           Escapes inside the head are accepted (-> Q2) or dropped here.  Survivors (about 2 %)
+//           are ballot-compacted into Q1 as (c, z).
+//   LONG    each lane holds one survivor and iterates it in chunks of kChunk steps until it escapes
+//           or reaches max_iter.  Lanes that finish refill from Q1 at chunk boundaries, so all 64
+//           lanes stay on deep orbits.  head_steps is chosen such that max_iter - head_steps is a
+//           multiple of kChunk: no lane ever needs a partial chunk.  Escaped samples go to Q2.
+//   REPLAY  each lane pops one accepted starting point from Q2, re-iterates it from z0 = c with the
+//           same step function and adds 1 to the histogram for every visited point (device-scope
+//           no-return u64 atomics).  Lanes refill from Q2 as they finish; a replay in flight
+//           is suspended (state stays in registers) when too few lanes are busy and resumed once
+//           Q2 has enough work again.
+//
+// A LONG lane knows its escape index only to within its chunk.  That is enough unless the chunk
+// straddles min_escape_iterations; then the sample is queued with a PROBE flag and the REPLAY lane
+// first re-iterates it without recording to get the exact index (rare: head_steps >= min_iter for
+// ordinary settings, and for large min_iter few orbits escape in that one chunk).
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kQ1Cap = 128;   // power of two
+constexpr int kQ2Cap = 256;   // power of two
+constexpr int kQ1Low = 16;    // run HEAD rounds while fewer survivors than this are queued
+constexpr int kReplayMin = 32;   // suspend REPLAY below this many busy lanes (unless draining)
+constexpr int kReplayBurst = 8;  // replay steps between refill checks
+
+struct WaveQueues {
+  double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];
+  double q2_cr[kQ2Cap], q2_ci[kQ2Cap];
+  uint32_t q2_flag[kQ2Cap];
+};
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs a) {
+  __shared__ WaveQueues queues[kWavesPerBlock];
+  WaveQueues &q = queues[threadIdx.x >> 6];
+
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = tid < a.n_threads;
+  const Canvas cv = make_canvas(a);
+  const int max_iter = a.max_iter;
+  const int min_iter = a.min_iter;
+  const int head_steps = a.head_steps;              // <= max_iter
+  const int long_steps = max_iter - head_steps;     // multiple of kChunk (0: no LONG stage)
+
+  LaneStats st;
+  Xorwow rng = {0, 0, 0, 0, 0, 0};
+  if (valid) rng = load_rng(a.states, a.n_threads, tid);
+
+  // wave-uniform scheduler state
+  uint32_t samples_left = a.samples_per_thread;
+  int q1_head = 0, q1_count = 0;
+  int q2_head = 0, q2_count = 0;
+  unsigned long long head_lane_steps = 0, long_lane_steps = 0;  // uniform step counters
+
+  // LONG lane state
+  double l_cr = 0, l_ci = 0, l_r = 0, l_i = 0;
+  int l_rem = 0;  // iterations left before max_iter; 0 = idle
+  // REPLAY lane state
+  double p_cr = 0, p_ci = 0, p_r = 0, p_i = 0;
+  bool p_act = false, p_probe = false;
+  int p_steps = 0;
+
+  for (;;) {
+    const bool input_done = (samples_left == 0);
+    const bool l_any = __ballot(l_rem > 0) != 0ull;
+    const bool draining = input_done && (q1_count == 0) && !l_any;
+    const int n_replaying = __popcll(__ballot(p_act));
+
+    // ---------------------------------------------------------------- REPLAY
+    if ((q2_count > 0 && q2_count + n_replaying >= 64) ||
+        (draining && (q2_count > 0 || n_replaying > 0))) {
+      for (;;) {
+        {  // refill idle lanes from Q2
+          const unsigned long long idle_mask = __ballot(!p_act);
+          const int n_idle = __popcll(idle_mask);
+          const int n = n_idle < q2_count ? n_idle : q2_count;
+          if (n > 0) {
+            const int rank = mask_prefix(idle_mask);
+            if (!p_act && rank < n) {
+              const int slot = (q2_head + rank) & (kQ2Cap - 1);
+              p_cr = q.q2_cr[slot];
+              p_ci = q.q2_ci[slot];
+              p_probe = q.q2_flag[slot] != 0u;
+              p_r = p_cr;
+              p_i = p_ci;
+              p_steps = 0;
+              p_act = true;
+              if (!p_probe) st.recorded++;
+            }
+            q2_head = (q2_head + n) & (kQ2Cap - 1);
+            q2_count -= n;
+          }
+        }
+        const int n_act = __popcll(__ballot(p_act));
+        if (n_act == 0) break;
+        if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
+
+        for (int b = 0; b < kReplayBurst; ++b) {
+          bool finished = false;
+          if (p_act) {
+            const double m = mandel_step(p_cr, p_ci, p_r, p_i);  // cudabrot.cu:357-359
+            p_steps++;
+            if (!p_probe) {
+              st.replay_steps++;
+              st.increments += increment_pixel_counter(p_r, p_i, a.hist, cv) ? 1ull : 0ull;
+            } else {
+              st.probe_steps++;
+            }
+            if (m > 4.0) {  // cudabrot.cu:363
+              if (p_probe) {
+                // exact escape index is p_steps - 1 (cudabrot.cu:336 returns the 0-based index)
+                if (p_steps - 1 >= min_iter) {
+                  p_probe = false;  // accepted: start over, recording this time
+                  p_r = p_cr;
+                  p_i = p_ci;
+                  p_steps = 0;
+                  st.recorded++;
+                } else {
+                  st.too_fast++;
+                  p_act = false;
+                  finished = true;
+                }
+              } else {
+                p_act = false;
+                finished = true;
+              }
+            } else if (p_steps > max_iter) {
+              // cannot happen: the orbit escaped within max_iter steps in the LONG/HEAD stage
+              st.status |= CB_STATUS_REPLAY_RUNAWAY;
+              p_act = false;
+              finished = true;
+            }
+          }
+          if (__ballot(finished) != 0ull && q2_count > 0) break;
+          if (__ballot(p_act) == 0ull) break;
+        }
+      }
+      if (draining) break;
+      continue;
+    }
+    if (draining) break;
+
+    // ---------------------------------------------------------------- HEAD
+    if (!input_done && q1_count < kQ1Low) {
+      samples_left--;
+      bool alive = false;
+      double cr = 0, ci = 0;
+      if (valid) {
+        cr = sample_coordinate(rng);  // cudabrot.cu:392
+        ci = sample_coordinate(rng);  // cudabrot.cu:393
+        st.samples++;
+        if (in_main_cardioid(cr, ci) || in_order2_bulb(cr, ci)) {  // cudabrot.cu:398
+          st.rejected++;
+        } else {
+          alive = true;
+        }
+      }
+      double r = cr, i = ci;
+      int k_esc = -1;
+      for (int s = 0; s < head_steps; ++s) {
+        const unsigned long long alive_mask = __ballot(alive);
+        if (alive_mask == 0ull) break;
+        head_lane_steps += (unsigned long long) __popcll(alive_mask);
+        if (alive) {
+          if (mandel_step(cr, ci, r, i) > 4.0) {  // cudabrot.cu:336
+            alive = false;
+            k_esc = s;
+          }
+        }
+      }
+      // escapes inside the head: the escape index is exact (cudabrot.cu:407-408)
+      bool accept = false;
+      if (k_esc >= 0) {
+        if (k_esc >= min_iter) {
+          accept = true;
+        } else {
+          st.too_fast++;
+        }
+      }
+      // survivors of the head
+      bool to_long = false;
+      if (alive) {
+        if (long_steps > 0) {
+          to_long = true;
+        } else {
+          st.never_escaped++;  // head_steps == max_iter: IterateMandelbrot returned max
+        }
+      }
+      {
+        const unsigned long long m2 = __ballot(accept);
+        if (m2 != 0ull) {
+          if (accept) {
+            const int slot = (q2_head + q2_count + mask_prefix(m2)) & (kQ2Cap - 1);
+            q.q2_cr[slot] = cr;
+            q.q2_ci[slot] = ci;
+            q.q2_flag[slot] = 0u;
+          }
+          q2_count += __popcll(m2);
+          if (q2_count > kQ2Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
+        }
+        const unsigned long long m1 = __ballot(to_long);
+        if (m1 != 0ull) {
+          if (to_long) {
+            const int slot = (q1_head + q1_count + mask_prefix(m1)) & (kQ1Cap - 1);
+            q.q1_cr[slot] = cr;
+            q.q1_ci[slot] = ci;
+            q.q1_r[slot] = r;
+            q.q1_i[slot] = i;
+          }
+          q1_count += __popcll(m1);
+          if (q1_count > kQ1Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
+        }
+      }
+      continue;
+    }
+
+    // ---------------------------------------------------------------- LONG
+    for (;;) {
+      {  // refill idle lanes from Q1
+        const unsigned long long idle_mask = __ballot(l_rem == 0);
+        const int n_idle = __popcll(idle_mask);
+        const int n = n_idle < q1_count ? n_idle : q1_count;
+        if (n > 0) {
+          const int rank = mask_prefix(idle_mask);
+          if (l_rem == 0 && rank < n) {
+            const int slot = (q1_head + rank) & (kQ1Cap - 1);
+            l_cr = q.q1_cr[slot];
+            l_ci = q.q1_ci[slot];
+            l_r = q.q1_r[slot];
+            l_i = q.q1_i[slot];
+            l_rem = long_steps;
+          }
+          q1_head = (q1_head + n) & (kQ1Cap - 1);
+          q1_count -= n;
+        }
+      }
+      const bool act = l_rem > 0;
+      if (__ballot(act) == 0ull) break;
+
+      // one chunk: kChunk steps, a lane leaves at its escape (cudabrot.cu:326-337)
+      // (a wave-uniform loop with a lane predicate, so that the step counter stays scalar)
+      bool esc = false;
+      {
+        bool live = act;
+        uint32_t chunk_lane_steps = 0;
+        for (int j = 0; j < kChunk; ++j) {
+          const unsigned long long live_mask = __ballot(live);
+          if (live_mask == 0ull) break;
+          chunk_lane_steps += (uint32_t) __popcll(live_mask);
+          if (live) {
+            if (mandel_step(l_cr, l_ci, l_r, l_i) > 4.0) {
+              esc = true;
+              live = false;
+            }
+          }
+        }
+        long_lane_steps += chunk_lane_steps;
+      }
+      bool push = false;
+      uint32_t flag = 0u;
+      if (act) {
+        if (esc) {
+          const int k_lo = max_iter - l_rem;  // escape index k is in [k_lo, k_lo + kChunk)
+          l_rem = 0;
+          if (k_lo >= min_iter) {
+            push = true;  // certainly k >= min_iter (and k < max_iter)
+          } else if (k_lo + kChunk <= min_iter) {
+            st.too_fast++;  // certainly k < min_iter
+          } else {
+            push = true;  // undecided: REPLAY re-derives k first
+            flag = 1u;
+          }
+        } else {
+          l_rem -= kChunk;
+          if (l_rem == 0) st.never_escaped++;
+        }
+      }
+      const unsigned long long m2 = __ballot(push);
+      if (m2 != 0ull) {
+        if (push) {
+          const int slot = (q2_head + q2_count + mask_prefix(m2)) & (kQ2Cap - 1);
+          q.q2_cr[slot] = l_cr;
+          q.q2_ci[slot] = l_ci;
+          q.q2_flag[slot] = flag;
+        }
+        q2_count += __popcll(m2);
+        if (q2_count > kQ2Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
+      }
+      // leave the stage when another one has work to do
+      if (q2_count + __popcll(__ballot(p_act)) >= 64) break;      // REPLAY can fill every lane
+      if (samples_left != 0 && q1_count < kQ1Low) break;          // HEAD must top up Q1
+    }
+  }
+
+  if (valid) store_rng(a.states, a.n_threads, tid, rng);
+  if (lane_id() == 0) st.iterate_steps += head_lane_steps + long_lane_steps;
+  flush_stats(a.counters, st);
+}
+
+hipError_t launch_draw_wave(const DrawArgs &a, hipStream_t stream) {
+  if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
+  const uint32_t threads = 64 * kWavesPerBlock;
+  const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
+  hipLaunchKernelGGL(draw_wave_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  return hipGetLastError();
+}
+
+int choose_head_steps(int max_iter, int min_iter) {
+  if (max_iter <= 0) return 0;
+  const int kMin = 8, kCap = 48;
+  int s = min_iter < kCap ? min_iter : kCap;
+  if (s < kMin) s = kMin;
+  if (max_iter <= s + kChunk) return max_iter;  // shallow runs: the head does all of it
+  s += (max_iter - s) % kChunk;
+  return s;
+}
+
+}  // namespace cb

@@ -1,0 +1,141 @@
+/*
+ * cudabrot_amd.h -- C ABI of the MI355X-native Buddhabrot hot path (libcudabrot_amd.so).
+ *
+ * The reference (yalue/cudabrot, one file: cudabrot.cu) has no FFI or plugin interface; its only
+ * internal boundary is the pair of kernel launches its host driver makes (last
+ * row).  The entry points below are exactly that boundary, as a C ABI: plain pointers and sizes, no
+ * C++ or torch types.  Each cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a hipError_t value (>0); cb_error_string() names it,
+ *    the way the reference prints cudaGetErrorString (cudabrot.cu:134-141);
+ *  - pointers named d_* are DEVICE pointers on the current HIP device, `stream` is a hipStream_t
+ *    passed as void* (NULL = the default stream); launches are asynchronous on that stream;
+ *  - the library never falls back to the CPU: without a usable HIP device every call fails.
+ */
+#ifndef CUDABROT_AMD_H_
+#define CUDABROT_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CB_ABI_VERSION 1
+
+/* Reference constants (cudabrot.cu:20,23,34,37). */
+#define CB_DEFAULT_BLOCK_SIZE 512
+#define CB_DEFAULT_BLOCK_COUNT 512
+#define CB_DEFAULT_THREADS (CB_DEFAULT_BLOCK_SIZE * CB_DEFAULT_BLOCK_COUNT)
+#define CB_SAMPLES_PER_THREAD 50
+#define CB_DEFAULT_RNG_SEED 1337ull
+
+/* `Pixel` (cudabrot.cu:43), widened to 64 bits as BASELINE.json's north_star asks: identical to the
+ * reference's uint32_t counts whenever no count reaches 2^32. */
+typedef uint64_t cb_pixel;
+
+/* `FractalDimensions` (cudabrot.cu:46-58): same fields, same order, same layout (56 bytes). */
+typedef struct {
+  int w;
+  int h;
+  double min_real;
+  double min_imag;
+  double max_real;
+  double max_imag;
+  double delta_real;
+  double delta_imag;
+} cb_fractal_dimensions;
+
+/* `IterationControl` (cudabrot.cu:62-67). */
+typedef struct {
+  int max_escape_iterations;
+  int min_escape_iterations;
+} cb_iteration_control;
+
+/* Exact workload counters, accumulated on the device; the reference has none. */
+typedef struct {
+  uint64_t samples;        /* starting points drawn (4 XORWOW outputs each)              */
+  uint64_t rejected;       /* inside the main cardioid / period-2 bulb (cudabrot.cu:398) */
+  uint64_t never_escaped;  /* IterateMandelbrot returned max (cudabrot.cu:407)           */
+  uint64_t too_fast;       /* escaped before min_escape_iterations (cudabrot.cu:408)     */
+  uint64_t recorded;       /* orbits replayed (cudabrot.cu:412)                          */
+  uint64_t iterate_steps;  /* z<-z^2+c iterations of IterateMandelbrot (cudabrot.cu:326) */
+  uint64_t replay_steps;   /* iterations of IterateAndRecord (cudabrot.cu:352)           */
+  uint64_t increments;     /* histogram increments (cudabrot.cu:312)                     */
+  uint64_t probe_steps;    /* extra iterations spent re-deriving an escape index         */
+  uint64_t status;         /* 0 = ok; nonzero = internal invariant violated (CB_STATUS_*) */
+} cb_counters;
+
+#define CB_STATUS_QUEUE_OVERFLOW 1u
+#define CB_STATUS_REPLAY_RUNAWAY 2u
+
+/* Kernel variants of cb_draw_buddhabrot. */
+#define CB_KERNEL_DEFAULT 0 /* wave-scheduled three-stage kernel (the product path)               */
+#define CB_KERNEL_SIMPLE 1  /* one lane = one reference thread, lock-step; a validation baseline  */
+
+/* RecomputePixelDeltas (cudabrot.cu:505-527).  Returns 1 and fills delta_* if the canvas is valid,
+ * else 0 and, if msg is not NULL, *msg points at the reference's message for the failed check. */
+int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg);
+
+/* Bytes of device memory cb_initialize_rng / cb_draw_buddhabrot need at d_states for n_threads
+ * generator states (replaces `block_size * block_count * sizeof(curandState_t)`, cudabrot.cu:177-178).
+ * Layout: six uint32 planes [x0 | x1 | x2 | x3 | x4 | d], each n_threads long. */
+size_t cb_rng_state_bytes(uint32_t n_threads);
+
+/* InitializeRNG<<<...>>>(seed, states) (cudabrot.cu:146-149,179): state t becomes the XORWOW
+ * generator rocrand_init(seed, first_subsequence + t, 0).  The reference always passes
+ * first_subsequence = 0; rank r of a multi-GPU run passes r * n_threads. */
+int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
+                      void *stream);
+
+/* DrawBuddhabrot<<<block_count, block_size>>>(dimensions, data, iterations, states)
+ * (cudabrot.cu:379-414,485-486) for n_threads threads, samples_per_thread samples each (the
+ * reference: 50 per launch; k reference passes in one launch = 50*k).  Adds to d_hist (w*h
+ * cb_pixel, row-major, row 0 = min_imag) with device-scope atomics, advances d_states, and adds to
+ * d_counters (may be NULL). */
+int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
+                       const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
+                       uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
+                       void *stream);
+
+/* ---- Renderer: SetupCUDA + RenderImage + the -s buffer, as an owned object ---------------------- */
+
+typedef struct cb_renderer cb_renderer;
+
+/* SetupCUDA (cudabrot.cu:153-189): selects `device`, allocates and zeroes the histogram, allocates
+ * and initialises n_threads generator states for subsequences [first_subsequence, +n_threads). */
+int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
+                       const cb_iteration_control *iterations, uint64_t seed,
+                       uint64_t first_subsequence, uint32_t n_threads);
+/* `passes` iterations of the loop body of RenderImage (cudabrot.cu:483-487), fused into as few
+ * launches as possible; returns after the device has finished them. */
+int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant);
+/* The cudaMemcpy of cudabrot.cu:496-497: host_out receives w*h cb_pixel. */
+int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out);
+/* The H2D copy of LoadInProgressBuffer (cudabrot.cu:256-257): REPLACES the device histogram. */
+int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in);
+int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out);
+/* Device pointer of the histogram, for a caller-side RCCL reduce. */
+cb_pixel *cb_renderer_device_histogram(cb_renderer *r);
+/* CleanupGlobals (cudabrot.cu:112-119). */
+void cb_renderer_destroy(cb_renderer *r);
+
+/* ---- Output stage (host side of the reference) -------------------------------------------------- */
+
+/* SetGrayscalePixels (cudabrot.cu:425-468) on a host histogram: gray_out receives w*h host-endian
+ * uint16; *max_out and *scale_out are the two numbers of the "Max value" line (cudabrot.cu:437). */
+void cb_set_grayscale_pixels(const cb_pixel *hist, int w, int h, double gamma, uint16_t *gray_out,
+                             uint64_t *max_out, double *scale_out);
+/* SaveImage (cudabrot.cu:548-577): byte-swaps gray in place and writes the binary PGM.  Returns 0,
+ * or 1/2/3 = open / header / pixel-data failure (the reference prints and carries on). */
+int cb_save_image(const char *path, uint16_t *gray, int w, int h);
+
+const char *cb_error_string(int code);
+int cb_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

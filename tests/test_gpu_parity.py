@@ -1,0 +1,188 @@
+"""GPU parity: the HIP hot path (through the C ABI) against the CPU oracle and the committed goldens.
+
+Bar: bit-exact u64 histograms and exact workload counters on the same seeded RNG stream
+(rocRAND XORWOW, seed 1337, subsequence = thread id, offset 0).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BOX = (-2.0, 2.0, -2.0, 2.0)
+COUNTER_KEYS = ("samples", "rejected", "never_escaped", "too_fast", "recorded", "iterate_steps",
+                "replay_steps", "increments")
+
+
+def gpu_render(cb, w, h, max_iter, min_iter, threads, passes, box=BOX, first=0, variant=None, fused=True):
+    variant = cb.CB_KERNEL_DEFAULT if variant is None else variant
+    dims = cb.FractalDimensions.make(w, h, box[0], box[1], box[2], box[3])
+    it = cb.IterationControl(max_iter, min_iter)
+    with cb.Renderer(dims, it, first_subsequence=first, n_threads=threads) as r:
+        if fused:
+            r.render_passes(passes, variant)
+        else:
+            for _ in range(passes):
+                r.render_passes(1, variant)
+        hist = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    return hist, cnt
+
+
+def assert_same(gpu, cpu):
+    gh, gc = gpu
+    ch, cc = cpu
+    assert gc["status"] == 0, "kernel reported an internal invariant violation: %r" % gc
+    if not np.array_equal(gh, ch):
+        diff = np.argwhere(gh != ch)
+        raise AssertionError("histograms differ at %d pixels, first %r: gpu %d cpu %d" % (
+            len(diff), tuple(diff[0]), gh[tuple(diff[0])], ch[tuple(diff[0])]))
+    for k in COUNTER_KEYS:
+        assert gc[k] == cc[k], "counter %s: gpu %d cpu %d" % (k, gc[k], cc[k])
+
+
+def test_goldens_wave_kernel(cb, oracle, golden):
+    """Every Appendix-B histogram config: hash, totals and the full histogram vs the oracle."""
+    for g in golden["histograms"]:
+        hist, cnt = gpu_render(cb, g["w"], g["h"], g["max_iter"], g["min_iter"], g["threads"], g["passes"],
+                               tuple(g["box"]))
+        assert cnt["status"] == 0
+        assert cnt["samples"] == g["samples"], g["name"]
+        assert int(hist.sum()) == g["increments"] == cnt["increments"], g["name"]
+        assert int(hist.max()) == g["max"], g["name"]
+        assert int((hist > 0).sum()) == g["nonzero"], g["name"]
+        assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"], g["name"]
+
+
+@pytest.mark.parametrize("variant_name", ["wave", "simple"])
+@pytest.mark.parametrize(
+    "cfg",
+    [
+        dict(w=256, h=256, max_iter=100, min_iter=20, threads=20000, passes=1),          # BASELINE C1
+        dict(w=1000, h=1000, max_iter=100, min_iter=20, threads=4096, passes=3),          # non-pow2 delta
+        dict(w=200, h=100, max_iter=100, min_iter=20, threads=8192, passes=2, box=(0.0, 1.0, 0.0, 0.5)),
+        dict(w=4096, h=4096, max_iter=2000, min_iter=20, threads=20000, passes=1),       # C2 shape
+        dict(w=4096, h=4096, max_iter=20000, min_iter=20, threads=20000, passes=1),      # C3 shape
+        dict(w=2000, h=1500, max_iter=2000, min_iter=20, threads=20000, passes=2, box=(-2.0, 2.0, -1.5, 1.5)),
+        dict(w=333, h=77, max_iter=500, min_iter=20, threads=1000, passes=4, box=(-1.7, 0.9, -0.3, 1.1)),
+    ],
+    ids=["c1", "nonpow2", "crop", "c2shape", "c3shape", "script_aspect", "odd_canvas"],
+)
+def test_full_histogram_vs_oracle(cb, oracle, cfg, variant_name):
+    variant = cb.CB_KERNEL_DEFAULT if variant_name == "wave" else cb.CB_KERNEL_SIMPLE
+    box = cfg.get("box", BOX)
+    gpu = gpu_render(cb, cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box,
+                     variant=variant)
+    cpu = oracle.render(cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    assert_same(gpu, cpu)
+
+
+@pytest.mark.parametrize(
+    "max_iter,min_iter",
+    [
+        (0, 20),        # IterateMandelbrot returns max at once: nothing recorded (cudabrot.cu:407)
+        (-5, 20),
+        (1, 0),
+        (7, 0),         # shallower than the head stage
+        (24, 0),        # head only, accept from iteration 0
+        (25, 3),
+        (40, 20),
+        (100, 0),       # -c 0: escapes inside the head are recorded
+        (100, 200),     # min > max: nothing recorded (cudabrot.cu:408)
+        (500, 20),      # generate_hires_color_image.sh "coarse"
+        (3000, 1000),   # min_iter beyond the head: chunk-straddle -> probe path
+        (3001, 1001),
+        (2999, 1007),
+        (8000, 1000),   # generate_hires_color_image.sh "medium"
+    ],
+)
+def test_iteration_window_edges(cb, oracle, max_iter, min_iter):
+    """Escape-window edge cases, including the probe path (min_iter inside a LONG chunk)."""
+    gpu = gpu_render(cb, 300, 300, max_iter, min_iter, 6000, 2)
+    cpu = oracle.render(300, 300, max_iter, min_iter, 6000, 2)
+    assert_same(gpu, cpu)
+
+
+@pytest.mark.parametrize("threads", [1, 63, 64, 65, 255, 256, 257, 1000])
+def test_ragged_thread_counts(cb, oracle, threads):
+    """Thread counts that do not fill a wave / a workgroup."""
+    gpu = gpu_render(cb, 128, 128, 300, 10, threads, 20)
+    cpu = oracle.render(128, 128, 300, 10, threads, 20)
+    assert_same(gpu, cpu)
+
+
+def test_fused_passes_equal_separate_launches(cb):
+    a = gpu_render(cb, 512, 512, 1000, 20, 8192, 6, fused=True)
+    b = gpu_render(cb, 512, 512, 1000, 20, 8192, 6, fused=False)
+    assert_same(a, b)
+
+
+def test_deterministic(cb):
+    """The reference's += races (cudabrot.cu:312); atomics make reruns identical."""
+    a = gpu_render(cb, 512, 512, 2000, 20, 16384, 2)
+    b = gpu_render(cb, 512, 512, 2000, 20, 16384, 2)
+    assert_same(a, b)
+
+
+@pytest.mark.parametrize("first", [262144, 7 * 262144, 2097151 - 4095, (1 << 40) + 12345])
+def test_subsequence_offsets(cb, oracle, first):
+    """Rank shards: subsequences [first, first + T), incl. ids of ranks 1 and 7."""
+    gpu = gpu_render(cb, 256, 256, 400, 20, 4096, 2, first=first)
+    cpu = oracle.render(256, 256, 400, 20, 4096, 2, first_subsequence=first)
+    assert_same(gpu, cpu)
+
+
+def test_two_shards_sum_to_one_big_run(cb):
+    """N-GPU run == 1-GPU run with N*T threads, bit for bit (here N = 2 on one device)."""
+    t = 8192
+    whole = gpu_render(cb, 400, 400, 1000, 20, 2 * t, 2)
+    s0 = gpu_render(cb, 400, 400, 1000, 20, t, 2, first=0)
+    s1 = gpu_render(cb, 400, 400, 1000, 20, t, 2, first=t)
+    assert np.array_equal(whole[0], s0[0] + s1[0])
+    for k in COUNTER_KEYS:
+        assert whole[1][k] == s0[1][k] + s1[1][k]
+
+
+def test_write_histogram_then_render_adds(cb, oracle):
+    """-s resume semantics: rendering adds to a loaded buffer (cudabrot.cu:256-257)."""
+    dims = cb.FractalDimensions.make(200, 200)
+    it = cb.IterationControl(200, 20)
+    base = (np.arange(200 * 200, dtype=np.uint64).reshape(200, 200) * 3) + (1 << 40)
+    with cb.Renderer(dims, it, n_threads=4096) as r:
+        r.write_histogram(base)
+        r.render_passes(2)
+        got = r.read_histogram()
+    cpu, _ = oracle.render(200, 200, 200, 20, 4096, 2)
+    assert np.array_equal(got, base + cpu)
+
+
+def test_low_level_entry_points_on_torch_memory(cb, oracle):
+    """cb_initialize_rng / cb_draw_buddhabrot on caller-owned device memory (torch as the allocator)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    t, w, h = 4096, 256, 256
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(300, 20)
+    states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    counters = torch.zeros(10, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
+    for _ in range(3):
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), t, 50, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream)
+    torch.cuda.synchronize()
+    got = hist.cpu().numpy().view(np.uint64).reshape(h, w)
+    cpu, cc = oracle.render(w, h, 300, 20, t, 3)
+    assert np.array_equal(got, cpu)
+    c = counters.cpu().numpy()
+    assert int(c[9]) == 0
+    assert int(c[0]) == cc["samples"] and int(c[7]) == cc["increments"]
+    # generator states after the run match the oracle's (planes x0..x4, d)
+    st = states.cpu().numpy().view(np.uint32).reshape(6, t)
+    ost = oracle.init_states(1337, 0, t)
+    oracle.render(w, h, 300, 20, t, 3, states=ost)
+    assert np.array_equal(st[5], ost["d"])
+    for k in range(5):
+        assert np.array_equal(st[k], ost["x"][:, k])
