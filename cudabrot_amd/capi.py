@@ -87,6 +87,33 @@ class Counters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.
+
+    The PyTorch wheel bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and links it by the
+    unversioned file name, so a process that loads /opt/rocm's copy through this library and then
+    uses torch.cuda ends up with two HIP/HSA runtimes, and the second one finds no GPU.  Loading
+    torch's copy first (globally) makes this library's DT_NEEDED ``libamdhip64.so.7`` resolve to it,
+    and a later ``import torch`` finds the same file.  Without torch installed (or with
+    CUDABROT_AMD_SYSTEM_HIP=1) the system runtime is used, as the `cudabrot` binary always does.
+    """
+    if os.environ.get("CUDABROT_AMD_SYSTEM_HIP") == "1":
+        return None
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return cand
+
+
 def _load():
     path = library_path()
     if not os.path.exists(path):
@@ -94,6 +121,7 @@ def _load():
             "cudabrot_amd: %s is missing -- build it with `make` (or __graft_entry__.build()); "
             "there is no CPU fallback" % path
         )
+    _share_torch_hip_runtime()
     lib_ = C.CDLL(path)
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     dims_p, it_p, cnt_p = C.POINTER(FractalDimensions), C.POINTER(IterationControl), C.POINTER(Counters)

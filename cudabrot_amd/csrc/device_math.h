@@ -53,11 +53,13 @@ __device__ __forceinline__ bool in_main_cardioid(double real, double imag) {
   return (q * (q + (real - 0.25))) < (imag_squared * 0.25);
 }
 
-// InOrder2Bulb, cudabrot.cu:294-298 (tmp + imag*imag is one FMA in the canonical sequence).
+// InOrder2Bulb, cudabrot.cu:294-298.  In the canonical sequence (what hipcc makes of the reference on
+// gfx950, and x86 clang likewise) the rounded imag*imag of the cardioid test is reused and the OTHER
+// product is fused: fma(tmp, tmp, imag*imag).
 __device__ __forceinline__ bool in_order2_bulb(double real, double imag) {
-  double tmp = real + 1.0;
-  tmp = tmp * tmp;
-  return __builtin_fma(imag, imag, tmp) < (1.0 / 16.0);
+  const double imag_squared = imag * imag;
+  const double tmp = real + 1.0;
+  return __builtin_fma(tmp, tmp, imag_squared) < (1.0 / 16.0);
 }
 
 // One z <- z^2 + c step (cudabrot.cu:331-333 and :357-359); returns |z|^2 as tested at :336/:363.

@@ -174,11 +174,12 @@ int orc_in_main_cardioid(double real, double imag) {
   return (q * (q + (real - 0.25))) < (imag_squared * 0.25);
 }
 
-/* cudabrot.cu:294-298; `tmp + imag*imag` contracts to one fma on gfx950 */
+/* cudabrot.cu:294-298.  hipcc (gfx950) and x86 clang both reuse the rounded imag*imag of the cardioid
+ * test and fuse the OTHER product: fma(tmp, tmp, imag*imag). */
 int orc_in_order2_bulb(double real, double imag) {
-  double tmp = real + 1;
-  tmp = tmp * tmp;
-  return __builtin_fma(imag, imag, tmp) < (1.0 / 16.0);
+  const double imag_squared = imag * imag;
+  const double tmp = real + 1;
+  return __builtin_fma(tmp, tmp, imag_squared) < (1.0 / 16.0);
 }
 
 /* One z <- z^2 + c step, cudabrot.cu:331-333 (= :357-359); returns |z|^2 as of :336 (= :363). */

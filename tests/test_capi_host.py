@@ -1,0 +1,96 @@
+"""The C-ABI library without a GPU: it loads, exports every declared symbol, and its host-side entry
+points (canvas validation, tone map, PGM writer) match the oracle.  No device compute here."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+def declared_symbols(repo_root):
+    text = open(os.path.join(repo_root, "include", "cudabrot_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(cb, repo_root):
+    names = declared_symbols(repo_root)
+    assert len(names) >= 15
+    raw = C.CDLL(cb.library_path())
+    for n in names:
+        assert hasattr(raw, n), "libcudabrot_amd.so does not export %s" % n
+    assert cb.lib.cb_abi_version() == 1
+
+
+def test_struct_layouts_match_the_reference_kernel_arguments(cb):
+    # FractalDimensions is 56 bytes, IterationControl 8 (cudabrot.cu:46-67)
+    assert C.sizeof(cb.FractalDimensions) == 56
+    assert C.sizeof(cb.IterationControl) == 8
+    assert C.sizeof(cb.Counters) == 80
+    assert cb.FractalDimensions.delta_real.offset == 40
+
+
+def test_rng_state_bytes(cb):
+    assert cb.rng_state_bytes(0) == 0
+    assert cb.rng_state_bytes(512 * 512) == 512 * 512 * 24
+
+
+def test_recompute_pixel_deltas_messages(cb):
+    """cudabrot.cu:505-527, messages verbatim (including the reference's swapped wording for imag)."""
+    d = cb.FractalDimensions(1000, 1000, -2.0, -2.0, 2.0, 2.0, 0, 0)
+    assert cb.recompute_pixel_deltas(d) == (True, None)
+    assert d.delta_real == 4.0 / 1000 and d.delta_imag == 4.0 / 1000
+    d = cb.FractalDimensions(0, 10, -2.0, -2.0, 2.0, 2.0, 0, 0)
+    assert cb.recompute_pixel_deltas(d) == (False, "Output width must be positive.")
+    d = cb.FractalDimensions(10, -1, -2.0, -2.0, 2.0, 2.0, 0, 0)
+    assert cb.recompute_pixel_deltas(d) == (False, "Output height must be positive.")
+    d = cb.FractalDimensions(10, 10, 1.0, -2.0, 1.0, 2.0, 0, 0)
+    assert cb.recompute_pixel_deltas(d) == (False, "Maximum real value must be greater than minimum real value.")
+    d = cb.FractalDimensions(10, 10, -2.0, 3.0, 2.0, 2.0, 0, 0)
+    assert cb.recompute_pixel_deltas(d) == (
+        False, "Minimum imaginary value must be greater than maximum imaginary value.")
+    d = cb.FractalDimensions.make(20000, 15000, -2.0, 2.0, -1.5, 1.5)  # generate_hires_color_image.sh
+    assert d.delta_real == 4.0 / 20000 and d.delta_imag == 3.0 / 15000
+
+
+def test_invalid_arguments_are_rejected_before_any_device_work(cb):
+    d = cb.FractalDimensions.make(16, 16)
+    it = cb.IterationControl(100, 20)
+    with pytest.raises(cb.CudabrotError):
+        cb.draw_buddhabrot(d, 0, it, 0, 64, 50)  # null device pointers
+    with pytest.raises(cb.CudabrotError):
+        cb.Renderer(d, it, n_threads=0)
+
+
+@pytest.mark.parametrize("gamma", [1.0, 2.2, 0.45, 0.0, -3.0])
+def test_set_grayscale_pixels_matches_oracle(cb, oracle, gamma):
+    hist, _ = oracle.render(150, 100, 300, 20, 2000, 2, (-2.0, 1.0, -1.0, 1.0))
+    hist[3, 4] += 1 << 33  # a count beyond 32 bits
+    g1, m1, s1 = cb.set_grayscale_pixels(hist, gamma)
+    g2, m2, s2 = oracle.set_grayscale_pixels(hist, gamma)
+    assert (m1, s1) == (m2, s2)
+    assert np.array_equal(g1, g2)
+    assert g1.max() == 65535 or gamma <= 0
+
+
+def test_set_grayscale_pixels_empty_histogram(cb, oracle):
+    """max == 0 -> scale = inf (cudabrot.cu:436); every pixel comes out 0."""
+    z = np.zeros((8, 8), dtype=np.uint64)
+    for gamma in (1.0, -1.0):
+        g, m, s = cb.set_grayscale_pixels(z, gamma)
+        assert m == 0 and s == float("inf") and not g.any()
+        assert np.array_equal(g, oracle.set_grayscale_pixels(z, gamma)[0])
+
+
+def test_save_image_bytes(cb, oracle, tmp_path):
+    gray = (np.arange(37 * 11, dtype=np.uint32) * 1777 % 65536).astype(np.uint16).reshape(11, 37)
+    path = str(tmp_path / "x.pgm")
+    assert cb.save_image(path, gray) == 0
+    data = open(path, "rb").read()
+    assert data.startswith(b"P5\n37 11\n65535\n")
+    assert data == oracle.encode_pgm(gray)
+    body = np.frombuffer(data[len(b"P5\n37 11\n65535\n"):], dtype=">u2").reshape(11, 37)
+    assert np.array_equal(body, gray)
+    assert cb.save_image(str(tmp_path / "no_such_dir" / "x.pgm"), gray) == 1  # open failure is reported
