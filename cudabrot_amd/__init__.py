@@ -11,6 +11,7 @@ from .capi import (  # noqa: F401
     CB_DEFAULT_THREADS,
     CB_KERNEL_DEFAULT,
     CB_KERNEL_SIMPLE,
+    CB_KERNEL_TIMED,
     CB_SAMPLES_PER_THREAD,
     Counters,
     CudabrotError,
@@ -33,6 +34,7 @@ __all__ = [
     "CB_DEFAULT_THREADS",
     "CB_KERNEL_DEFAULT",
     "CB_KERNEL_SIMPLE",
+    "CB_KERNEL_TIMED",
     "CB_SAMPLES_PER_THREAD",
     "Counters",
     "CudabrotError",

@@ -19,6 +19,7 @@ CB_SAMPLES_PER_THREAD = 50  # cudabrot.cu:34
 CB_DEFAULT_RNG_SEED = 1337  # cudabrot.cu:37
 CB_KERNEL_DEFAULT = 0
 CB_KERNEL_SIMPLE = 1
+CB_KERNEL_TIMED = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -78,8 +79,12 @@ class Counters(C.Structure):
             "iterate_steps",
             "replay_steps",
             "increments",
-            "probe_steps",
+            "reserved",
             "status",
+            "cycles_head",
+            "cycles_long",
+            "cycles_replay",
+            "cycles_total",
         )
     ]
 

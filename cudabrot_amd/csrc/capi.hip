@@ -150,7 +150,9 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (kernel_variant) {
     case CB_KERNEL_DEFAULT:
-      return (int) cb::launch_draw_wave(a, s);
+      return (int) cb::launch_draw_wave(a, false, s);
+    case CB_KERNEL_TIMED:
+      return (int) cb::launch_draw_wave(a, true, s);
     case CB_KERNEL_SIMPLE:
       return (int) cb::launch_draw_simple(a, s);
     default:

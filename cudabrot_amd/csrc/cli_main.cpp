@@ -144,7 +144,9 @@ const std::vector<Flag> &flag_table() {
        [](Settings &s, long i, double, const char *) { s.fixed_passes = i < 0 ? 0 : i; }},
       {"--kernel", Value::kText, nullptr, false,
        [](Settings &s, long, double, const char *t) {
-         s.kernel_variant = (strcmp(t, "simple") == 0) ? CB_KERNEL_SIMPLE : CB_KERNEL_DEFAULT;
+         s.kernel_variant = (strcmp(t, "simple") == 0)  ? CB_KERNEL_SIMPLE
+                            : (strcmp(t, "timed") == 0) ? CB_KERNEL_TIMED
+                                                        : CB_KERNEL_DEFAULT;
        }},
       {"--stats", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.print_stats = true; }},
@@ -413,12 +415,15 @@ class Run {
     fprintf(stderr,
             "{\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
             "\"recorded\": %llu, \"iterate_steps\": %llu, \"replay_steps\": %llu, "
-            "\"increments\": %llu, \"probe_steps\": %llu, \"status\": %llu}\n",
+            "\"increments\": %llu, \"status\": %llu, \"cycles_head\": %llu, \"cycles_long\": %llu, "
+            "\"cycles_replay\": %llu, \"cycles_total\": %llu}\n",
             (unsigned long long) c.samples, (unsigned long long) c.rejected,
             (unsigned long long) c.never_escaped, (unsigned long long) c.too_fast,
             (unsigned long long) c.recorded, (unsigned long long) c.iterate_steps,
             (unsigned long long) c.replay_steps, (unsigned long long) c.increments,
-            (unsigned long long) c.probe_steps, (unsigned long long) c.status);
+            (unsigned long long) c.status, (unsigned long long) c.cycles_head,
+            (unsigned long long) c.cycles_long, (unsigned long long) c.cycles_replay,
+            (unsigned long long) c.cycles_total);
   }
 
   void save_image() {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0

@@ -35,7 +35,7 @@ struct DrawArgs {
 hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads,
                            uint32_t *d_states, const uint32_t *d_matrices, hipStream_t stream);
 hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream);
-hipError_t launch_draw_wave(const DrawArgs &a, hipStream_t stream);
+hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
 
 // Steps per chunk of the long-iterate stage; head_steps is chosen so that
 // (max_iter - head_steps) % kChunk == 0.

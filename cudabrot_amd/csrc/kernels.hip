@@ -132,7 +132,7 @@ __device__ __forceinline__ void store_rng(uint32_t *states, uint32_t n, uint32_t
 // Per-lane statistics, summed over the wave at kernel end (one atomic per counter per wave).
 struct LaneStats {
   unsigned long long samples = 0, rejected = 0, never_escaped = 0, too_fast = 0, recorded = 0,
-                     iterate_steps = 0, replay_steps = 0, increments = 0, probe_steps = 0,
+                     iterate_steps = 0, replay_steps = 0, increments = 0, reserved = 0,
                      status = 0;
 };
 
@@ -141,7 +141,7 @@ __device__ __forceinline__ void flush_stats(cb_counters *counters, const LaneSta
   const unsigned long long v[10] = {
       wave_sum(s.samples),       wave_sum(s.rejected),     wave_sum(s.never_escaped),
       wave_sum(s.too_fast),      wave_sum(s.recorded),     wave_sum(s.iterate_steps),
-      wave_sum(s.replay_steps),  wave_sum(s.increments),   wave_sum(s.probe_steps),
+      wave_sum(s.replay_steps),  wave_sum(s.increments),   wave_sum(s.reserved),
       wave_sum(s.status)};
   if (lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(counters);
@@ -219,7 +219,7 @@ hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream) {
 // draw_wave_kernel: the product path
 // ------------------------------------------------------------------------------------------------
 //
-// Why: at max_iter = 20000 a sample needs 168 iterations on average but 89 % of samples need < 20
+// Why: at max_iter = 20000 a sample needs 168 iterations on average, but 89 % of samples need < 20
 // and 0.8 % need all 20000; one lane per reference thread in lock-step keeps ~2 % of the lanes busy
 // (SURVEY.md H2).  Histogram increments commute, so ANY schedule of the fixed multiset of samples
 // {(subsequence t, sample n)} gives the identical histogram, provided each subsequence is consumed
@@ -228,23 +228,29 @@ hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream) {
 // decoupled by two wave-private queues in LDS (no barriers: a wave's LDS operations are in order):
 //
 //   HEAD    all 64 lanes draw a starting point (4 XORWOW outputs, registers only), apply the
-//           cardioid / bulb test and run the first head_steps iterations under a lane mask.
-//           Escapes inside the head are accepted (-> Q2) or dropped here.  Survivors (about 2 %)
+//           cardioid / bulb test and run the first head_steps iterations under the EXEC mask.
+//           Escapes inside the head are dropped (k < min_iter) or accepted (-> Q2) here.  Survivors
 //           are ballot-compacted into Q1 as (c, z).
 //   LONG    each lane holds one survivor and iterates it in chunks of kChunk steps until it escapes
-//           or reaches max_iter.  Lanes that finish refill from Q1 at chunk boundaries, so all 64
-//           lanes stay on deep orbits.  head_steps is chosen such that max_iter - head_steps is a
-//           multiple of kChunk: no lane ever needs a partial chunk.  Escaped samples go to Q2.
+//           or reaches max_iter; v_cmpx removes a lane from EXEC at its escape.  Lanes that finish
+//           refill from Q1 at chunk boundaries, so all 64 lanes stay on deep orbits.  Escaped
+//           samples whose chunk lies at or above min_iter go to Q2.
 //   REPLAY  each lane pops one accepted starting point from Q2, re-iterates it from z0 = c with the
 //           same step function and adds 1 to the histogram for every visited point (device-scope
-//           no-return u64 atomics).  Lanes refill from Q2 as they finish; a replay in flight
-//           is suspended (state stays in registers) when too few lanes are busy and resumed once
-//           Q2 has enough work again.
+//           no-return u64 atomics).  Lanes refill from Q2 as they finish; a replay in flight is
+//           suspended (state stays in registers) when too few lanes are busy and resumed once Q2
+//           has enough work again.
 //
-// A LONG lane knows its escape index only to within its chunk.  That is enough unless the chunk
-// straddles min_escape_iterations; then the sample is queued with a PROBE flag and the REPLAY lane
-// first re-iterates it without recording to get the exact index (rare: head_steps >= min_iter for
-// ordinary settings, and for large min_iter few orbits escape in that one chunk).
+// A LONG lane knows its escape index only to within its chunk.  head_steps is chosen so that
+// min_iter - head_steps is a multiple of kChunk (choose_head_steps): no chunk straddles min_iter,
+// so "which chunk" decides accept / too-fast exactly.  max_iter - head_steps need not be a
+// multiple; a lane's last, shorter chunk runs in a loop with a run-time trip count (once per
+// never-escaping sample).
+//
+// The step loops are hand-written gfx950 assembly: per iteration 7 fp64 VALU instructions + one
+// v_cmpx (the compare that also clears the lane's EXEC bit) and 2 scalar instructions for the exact
+// lane-step count.  The compiler's own lowering of the same loop spent ~35 scalar instructions per
+// step on mask bookkeeping, and the one scalar unit of a CU serves all four SIMDs.
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Cap = 128;   // power of two
@@ -256,37 +262,124 @@ constexpr int kReplayBurst = 8;  // replay steps between refill checks
 struct WaveQueues {
   double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];
   double q2_cr[kQ2Cap], q2_ci[kQ2Cap];
-  uint32_t q2_flag[kQ2Cap];
 };
 
+// One z <- z^2 + c step on the lanes in EXEC, in the canonical order of device_math.h's mandel_step:
+//   a = i*i; b = r+r; a = fma(r,r,-a); i = fma(b,i,ci); r = cr + a; a = r*r; a = fma(i,i,a)
+// then EXEC &= !(4.0 < a) (v_cmpx: a lane leaves at its escape, cudabrot.cu:336), after adding the
+// number of lanes that execute the step to the scalar counter.
+#define CB_STEP                                       \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "v_add_f64 %[b], %[r], %[r]\n\t"                    \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"             \
+  "v_add_f64 %[r], %[cr], %[a]\n\t"                   \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, 4.0, %[a]\n\t"
+#define CB_STEP4 CB_STEP CB_STEP CB_STEP CB_STEP
+#define CB_STEP16 CB_STEP4 CB_STEP4 CB_STEP4 CB_STEP4
+
+// kChunk steps on the lanes of `mask` (wave-uniform).  Returns the lanes that escaped; r, i of the
+// other lanes advance by kChunk iterations; lane_steps receives the executed lane-steps.
+__device__ __forceinline__ unsigned long long iterate_chunk(unsigned long long mask, double cr,
+                                                            double ci, double &r, double &i,
+                                                            uint32_t &lane_steps) {
+  static_assert(kChunk == 16, "CB_STEP16 is unrolled for 16 steps");
+  unsigned long long save, escaped;
+  uint32_t cnt, tmp;
+  double a, b;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      CB_STEP16
+      "s_andn2_b64 %[esc], %[mask], exec\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [r] "+v"(r), [i] "+v"(i), [a] "=&v"(a), [b] "=&v"(b), [save] "=&s"(save),
+        [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp)
+      : [mask] "s"(mask), [cr] "v"(cr), [ci] "v"(ci)
+      : "vcc", "scc");
+  lane_steps = cnt;
+  return escaped;
+}
+
+// n steps (wave-uniform run-time count) on the lanes of `mask`, leaving early once every lane has
+// escaped.  Same contract as iterate_chunk.
+__device__ __forceinline__ unsigned long long iterate_steps(unsigned long long mask, uint32_t n,
+                                                            double cr, double ci, double &r,
+                                                            double &i, uint32_t &lane_steps) {
+  unsigned long long save, escaped;
+  uint32_t cnt, tmp, ctr;
+  double a, b;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "1:\n\t"
+      CB_STEP
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_andn2_b64 %[esc], %[mask], exec\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [r] "+v"(r), [i] "+v"(i), [a] "=&v"(a), [b] "=&v"(b), [save] "=&s"(save),
+        [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr)
+      : [mask] "s"(mask), [n] "s"(n), [cr] "v"(cr), [ci] "v"(ci)
+      : "vcc", "scc");
+  lane_steps = cnt;
+  return escaped;
+}
+
+__device__ __forceinline__ bool lane_in(unsigned long long mask) {
+  return (mask >> lane_id()) & 1ull;
+}
+
+template <bool kTimed>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs a) {
   __shared__ WaveQueues queues[kWavesPerBlock];
   WaveQueues &q = queues[threadIdx.x >> 6];
 
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = tid < a.n_threads;
+  const unsigned long long valid_mask = __ballot(valid);
   const Canvas cv = make_canvas(a);
   const int max_iter = a.max_iter;
   const int min_iter = a.min_iter;
-  const int head_steps = a.head_steps;              // <= max_iter
-  const int long_steps = max_iter - head_steps;     // multiple of kChunk (0: no LONG stage)
+  const int head_steps = a.head_steps;                    // <= max_iter
+  const int long_steps = max_iter - head_steps;           // iterations left to the LONG stage
+  const int tail_steps = long_steps % kChunk;             // a lane's last, shorter chunk
+  // head phases: escapes at k < min_iter are too fast, at k >= min_iter they are accepted
+  const uint32_t head_a = (uint32_t) (min_iter < 0 ? 0 : (min_iter < head_steps ? min_iter : head_steps));
+  const uint32_t head_b = (uint32_t) head_steps - head_a;
 
-  LaneStats st;
   Xorwow rng = {0, 0, 0, 0, 0, 0};
   if (valid) rng = load_rng(a.states, a.n_threads, tid);
 
-  // wave-uniform scheduler state
+  // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t samples_left = a.samples_per_thread;
   int q1_head = 0, q1_count = 0;
   int q2_head = 0, q2_count = 0;
-  unsigned long long head_lane_steps = 0, long_lane_steps = 0;  // uniform step counters
+  unsigned long long n_rejected = 0, n_never = 0, n_too_fast = 0, n_recorded = 0, n_iterate = 0,
+                     n_replay = 0, n_incr = 0, status = 0;
+  unsigned long long t_head = 0, t_long = 0, t_replay = 0;
+  const unsigned long long t_start = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
 
   // LONG lane state
   double l_cr = 0, l_ci = 0, l_r = 0, l_i = 0;
   int l_rem = 0;  // iterations left before max_iter; 0 = idle
   // REPLAY lane state
   double p_cr = 0, p_ci = 0, p_r = 0, p_i = 0;
-  bool p_act = false, p_probe = false;
+  bool p_act = false;
   int p_steps = 0;
 
   for (;;) {
@@ -298,6 +391,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
     // ---------------------------------------------------------------- REPLAY
     if ((q2_count > 0 && q2_count + n_replaying >= 64) ||
         (draining && (q2_count > 0 || n_replaying > 0))) {
+      const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       for (;;) {
         {  // refill idle lanes from Q2
           const unsigned long long idle_mask = __ballot(!p_act);
@@ -309,15 +403,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
               const int slot = (q2_head + rank) & (kQ2Cap - 1);
               p_cr = q.q2_cr[slot];
               p_ci = q.q2_ci[slot];
-              p_probe = q.q2_flag[slot] != 0u;
               p_r = p_cr;
               p_i = p_ci;
               p_steps = 0;
               p_act = true;
-              if (!p_probe) st.recorded++;
             }
             q2_head = (q2_head + n) & (kQ2Cap - 1);
             q2_count -= n;
+            n_recorded += (unsigned long long) n;
           }
         }
         const int n_act = __popcll(__ballot(p_act));
@@ -325,45 +418,27 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
         if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
 
         for (int b = 0; b < kReplayBurst; ++b) {
-          bool finished = false;
+          const unsigned long long act_mask = __ballot(p_act);
+          if (act_mask == 0ull) break;
+          n_replay += (unsigned long long) __popcll(act_mask);
+          bool done = false, hit = false;
           if (p_act) {
-            const double m = mandel_step(p_cr, p_ci, p_r, p_i);  // cudabrot.cu:357-359
+            const double m = mandel_step(p_cr, p_ci, p_r, p_i);       // cudabrot.cu:357-359
+            hit = increment_pixel_counter(p_r, p_i, a.hist, cv);      // cudabrot.cu:360
             p_steps++;
-            if (!p_probe) {
-              st.replay_steps++;
-              st.increments += increment_pixel_counter(p_r, p_i, a.hist, cv) ? 1ull : 0ull;
-            } else {
-              st.probe_steps++;
+            done = m > 4.0;                                           // cudabrot.cu:363
+            if (!done && p_steps > max_iter) {
+              // cannot happen: the orbit escaped within max_iter steps in the HEAD/LONG stage
+              status |= CB_STATUS_REPLAY_RUNAWAY;
+              done = true;
             }
-            if (m > 4.0) {  // cudabrot.cu:363
-              if (p_probe) {
-                // exact escape index is p_steps - 1 (cudabrot.cu:336 returns the 0-based index)
-                if (p_steps - 1 >= min_iter) {
-                  p_probe = false;  // accepted: start over, recording this time
-                  p_r = p_cr;
-                  p_i = p_ci;
-                  p_steps = 0;
-                  st.recorded++;
-                } else {
-                  st.too_fast++;
-                  p_act = false;
-                  finished = true;
-                }
-              } else {
-                p_act = false;
-                finished = true;
-              }
-            } else if (p_steps > max_iter) {
-              // cannot happen: the orbit escaped within max_iter steps in the LONG/HEAD stage
-              st.status |= CB_STATUS_REPLAY_RUNAWAY;
-              p_act = false;
-              finished = true;
-            }
+            if (done) p_act = false;
           }
-          if (__ballot(finished) != 0ull && q2_count > 0) break;
-          if (__ballot(p_act) == 0ull) break;
+          n_incr += (unsigned long long) __popcll(__ballot(hit));
+          if (__ballot(done) != 0ull && q2_count > 0) break;
         }
       }
+      if (kTimed) t_replay += __builtin_amdgcn_s_memtime() - t0;
       if (draining) break;
       continue;
     }
@@ -371,79 +446,61 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
 
     // ---------------------------------------------------------------- HEAD
     if (!input_done && q1_count < kQ1Low) {
+      const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       samples_left--;
       bool alive = false;
       double cr = 0, ci = 0;
       if (valid) {
         cr = sample_coordinate(rng);  // cudabrot.cu:392
         ci = sample_coordinate(rng);  // cudabrot.cu:393
-        st.samples++;
-        if (in_main_cardioid(cr, ci) || in_order2_bulb(cr, ci)) {  // cudabrot.cu:398
-          st.rejected++;
-        } else {
-          alive = true;
-        }
+        alive = !(in_main_cardioid(cr, ci) || in_order2_bulb(cr, ci));  // cudabrot.cu:398
       }
+      unsigned long long alive_mask = __ballot(alive);
+      n_rejected += (unsigned long long) __popcll(valid_mask & ~alive_mask);
       double r = cr, i = ci;
-      int k_esc = -1;
-      for (int s = 0; s < head_steps; ++s) {
-        const unsigned long long alive_mask = __ballot(alive);
-        if (alive_mask == 0ull) break;
-        head_lane_steps += (unsigned long long) __popcll(alive_mask);
-        if (alive) {
-          if (mandel_step(cr, ci, r, i) > 4.0) {  // cudabrot.cu:336
-            alive = false;
-            k_esc = s;
-          }
-        }
+      unsigned long long accept_mask = 0ull;
+      uint32_t steps = 0;
+      if (alive_mask != 0ull && head_a != 0u) {  // k in [0, head_a): too fast (cudabrot.cu:408)
+        const unsigned long long esc = iterate_steps(alive_mask, head_a, cr, ci, r, i, steps);
+        n_iterate += steps;
+        n_too_fast += (unsigned long long) __popcll(esc);
+        alive_mask &= ~esc;
       }
-      // escapes inside the head: the escape index is exact (cudabrot.cu:407-408)
-      bool accept = false;
-      if (k_esc >= 0) {
-        if (k_esc >= min_iter) {
-          accept = true;
-        } else {
-          st.too_fast++;
-        }
+      if (alive_mask != 0ull && head_b != 0u) {  // k in [head_a, head_steps): accepted
+        accept_mask = iterate_steps(alive_mask, head_b, cr, ci, r, i, steps);
+        n_iterate += steps;
+        alive_mask &= ~accept_mask;
       }
-      // survivors of the head
-      bool to_long = false;
-      if (alive) {
+      if (accept_mask != 0ull) {
+        if (lane_in(accept_mask)) {
+          const int slot = (q2_head + q2_count + mask_prefix(accept_mask)) & (kQ2Cap - 1);
+          q.q2_cr[slot] = cr;
+          q.q2_ci[slot] = ci;
+        }
+        q2_count += __popcll(accept_mask);
+        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+      }
+      if (alive_mask != 0ull) {  // survivors of the head
         if (long_steps > 0) {
-          to_long = true;
-        } else {
-          st.never_escaped++;  // head_steps == max_iter: IterateMandelbrot returned max
-        }
-      }
-      {
-        const unsigned long long m2 = __ballot(accept);
-        if (m2 != 0ull) {
-          if (accept) {
-            const int slot = (q2_head + q2_count + mask_prefix(m2)) & (kQ2Cap - 1);
-            q.q2_cr[slot] = cr;
-            q.q2_ci[slot] = ci;
-            q.q2_flag[slot] = 0u;
-          }
-          q2_count += __popcll(m2);
-          if (q2_count > kQ2Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
-        }
-        const unsigned long long m1 = __ballot(to_long);
-        if (m1 != 0ull) {
-          if (to_long) {
-            const int slot = (q1_head + q1_count + mask_prefix(m1)) & (kQ1Cap - 1);
+          if (lane_in(alive_mask)) {
+            const int slot = (q1_head + q1_count + mask_prefix(alive_mask)) & (kQ1Cap - 1);
             q.q1_cr[slot] = cr;
             q.q1_ci[slot] = ci;
             q.q1_r[slot] = r;
             q.q1_i[slot] = i;
           }
-          q1_count += __popcll(m1);
-          if (q1_count > kQ1Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
+          q1_count += __popcll(alive_mask);
+          if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        } else {
+          n_never += (unsigned long long) __popcll(alive_mask);  // head_steps == max_iter
         }
       }
+      if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
       continue;
     }
 
     // ---------------------------------------------------------------- LONG
+    const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
       {  // refill idle lanes from Q1
         const unsigned long long idle_mask = __ballot(l_rem == 0);
@@ -463,84 +520,94 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
           q1_count -= n;
         }
       }
-      const bool act = l_rem > 0;
-      if (__ballot(act) == 0ull) break;
+      const unsigned long long full_mask = __ballot(l_rem >= kChunk);
+      const unsigned long long tail_mask = __ballot(l_rem > 0 && l_rem < kChunk);
+      if ((full_mask | tail_mask) == 0ull) break;
 
-      // one chunk: kChunk steps, a lane leaves at its escape (cudabrot.cu:326-337)
-      // (a wave-uniform loop with a lane predicate, so that the step counter stays scalar)
-      bool esc = false;
-      {
-        bool live = act;
-        uint32_t chunk_lane_steps = 0;
-        for (int j = 0; j < kChunk; ++j) {
-          const unsigned long long live_mask = __ballot(live);
-          if (live_mask == 0ull) break;
-          chunk_lane_steps += (uint32_t) __popcll(live_mask);
-          if (live) {
-            if (mandel_step(l_cr, l_ci, l_r, l_i) > 4.0) {
-              esc = true;
-              live = false;
-            }
-          }
-        }
-        long_lane_steps += chunk_lane_steps;
+      unsigned long long esc = 0ull;
+      uint32_t steps = 0;
+      if (tail_mask != 0ull) {  // last, shorter chunk of these lanes: exactly tail_steps iterations
+        esc = iterate_steps(tail_mask, (uint32_t) tail_steps, l_cr, l_ci, l_r, l_i, steps);
+        n_iterate += steps;
+        n_never += (unsigned long long) __popcll(tail_mask & ~esc);
       }
-      bool push = false;
-      uint32_t flag = 0u;
-      if (act) {
-        if (esc) {
-          const int k_lo = max_iter - l_rem;  // escape index k is in [k_lo, k_lo + kChunk)
-          l_rem = 0;
-          if (k_lo >= min_iter) {
-            push = true;  // certainly k >= min_iter (and k < max_iter)
-          } else if (k_lo + kChunk <= min_iter) {
-            st.too_fast++;  // certainly k < min_iter
-          } else {
-            push = true;  // undecided: REPLAY re-derives k first
-            flag = 1u;
-          }
-        } else {
-          l_rem -= kChunk;
-          if (l_rem == 0) st.never_escaped++;
-        }
+      if (full_mask != 0ull) {
+        esc |= iterate_chunk(full_mask, l_cr, l_ci, l_r, l_i, steps);
+        n_iterate += steps;
       }
-      const unsigned long long m2 = __ballot(push);
-      if (m2 != 0ull) {
+      // Bookkeeping.  A lane's chunk covered escape indices [k_lo, k_lo + chunk length) with
+      // k_lo = max_iter - l_rem; min_iter - head_steps is a multiple of kChunk, so the whole chunk
+      // is on one side of min_iter (cudabrot.cu:407-408).
+      const bool escaped = lane_in(esc);
+      const bool in_full = lane_in(full_mask);
+      const bool in_tail = lane_in(tail_mask);
+      const bool push = escaped && (max_iter - l_rem >= min_iter);
+      n_too_fast += (unsigned long long) __popcll(__ballot(escaped && !push));
+      if (escaped || in_tail) {
+        l_rem = 0;
+      } else if (in_full) {
+        l_rem -= kChunk;
+      }
+      n_never += (unsigned long long) __popcll(__ballot(in_full && !escaped && l_rem == 0));
+      const unsigned long long push_mask = __ballot(push);
+      if (push_mask != 0ull) {
         if (push) {
-          const int slot = (q2_head + q2_count + mask_prefix(m2)) & (kQ2Cap - 1);
+          const int slot = (q2_head + q2_count + mask_prefix(push_mask)) & (kQ2Cap - 1);
           q.q2_cr[slot] = l_cr;
           q.q2_ci[slot] = l_ci;
-          q.q2_flag[slot] = flag;
         }
-        q2_count += __popcll(m2);
-        if (q2_count > kQ2Cap) st.status |= CB_STATUS_QUEUE_OVERFLOW;
+        q2_count += __popcll(push_mask);
+        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
       }
       // leave the stage when another one has work to do
       if (q2_count + __popcll(__ballot(p_act)) >= 64) break;      // REPLAY can fill every lane
       if (samples_left != 0 && q1_count < kQ1Low) break;          // HEAD must top up Q1
     }
+    if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
   }
 
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
-  if (lane_id() == 0) st.iterate_steps += head_lane_steps + long_lane_steps;
-  flush_stats(a.counters, st);
+  if (a.counters && lane_id() == 0) {
+    unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
+    const unsigned long long n_samples =
+        (unsigned long long) __popcll(valid_mask) * (unsigned long long) a.samples_per_thread;
+    const unsigned long long v[9] = {n_samples, n_rejected, n_never,  n_too_fast, n_recorded,
+                                     n_iterate, n_replay,   n_incr,   0ull};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (status) __hip_atomic_fetch_or(c + 9, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kTimed) {
+      const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_start;
+      __hip_atomic_fetch_add(c + 10, t_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 11, t_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 12, t_replay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 13, t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
-hipError_t launch_draw_wave(const DrawArgs &a, hipStream_t stream) {
+hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
-  hipLaunchKernelGGL(draw_wave_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  if (timed) {
+    hipLaunchKernelGGL(draw_wave_kernel<true>, dim3(blocks), dim3(threads), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(draw_wave_kernel<false>, dim3(blocks), dim3(threads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 
+// Iterations done by the HEAD stage.  min_iter - head_steps is a multiple of kChunk whenever
+// min_iter lies beyond the head, so that no LONG chunk straddles min_iter.
 int choose_head_steps(int max_iter, int min_iter) {
   if (max_iter <= 0) return 0;
-  const int kMin = 8, kCap = 48;
-  int s = min_iter < kCap ? min_iter : kCap;
-  if (s < kMin) s = kMin;
-  if (max_iter <= s + kChunk) return max_iter;  // shallow runs: the head does all of it
-  s += (max_iter - s) % kChunk;
+  const int kHeadMin = 4;
+  int s = kHeadMin;
+  if (min_iter > kHeadMin) s += (min_iter - kHeadMin) % kChunk;
+  if (s > max_iter) s = max_iter;  // shallow runs: the head does all of it
   return s;
 }
 

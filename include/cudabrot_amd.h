@@ -64,8 +64,10 @@ typedef struct {
   uint64_t iterate_steps;  /* z<-z^2+c iterations of IterateMandelbrot (cudabrot.cu:326) */
   uint64_t replay_steps;   /* iterations of IterateAndRecord (cudabrot.cu:352)           */
   uint64_t increments;     /* histogram increments (cudabrot.cu:312)                     */
-  uint64_t probe_steps;    /* extra iterations spent re-deriving an escape index         */
+  uint64_t reserved;       /* always 0                                                   */
   uint64_t status;         /* 0 = ok; nonzero = internal invariant violated (CB_STATUS_*) */
+  /* CB_KERNEL_TIMED only (else 0): shader-clock cycles summed over waves, per stage and in total */
+  uint64_t cycles_head, cycles_long, cycles_replay, cycles_total;
 } cb_counters;
 
 #define CB_STATUS_QUEUE_OVERFLOW 1u
@@ -74,6 +76,7 @@ typedef struct {
 /* Kernel variants of cb_draw_buddhabrot. */
 #define CB_KERNEL_DEFAULT 0 /* wave-scheduled three-stage kernel (the product path)               */
 #define CB_KERNEL_SIMPLE 1  /* one lane = one reference thread, lock-step; a validation baseline  */
+#define CB_KERNEL_TIMED 2   /* the default kernel with per-stage s_memtime stamps (diagnostic build) */
 
 /* RecomputePixelDeltas (cudabrot.cu:505-527).  Returns 1 and fills delta_* if the canvas is valid,
  * else 0 and, if msg is not NULL, *msg points at the reference's message for the failed check. */
