@@ -19,12 +19,14 @@ from .capi import (  # noqa: F401
     IterationControl,
     Renderer,
     draw_buddhabrot,
+    flush_scatter,
     initialize_rng,
     lib,
     library_path,
     recompute_pixel_deltas,
     rng_state_bytes,
     save_image,
+    scatter_workspace_bytes,
     set_grayscale_pixels,
 )
 from .sharding import shard_subsequences  # noqa: F401
@@ -42,12 +44,14 @@ __all__ = [
     "IterationControl",
     "Renderer",
     "draw_buddhabrot",
+    "flush_scatter",
     "initialize_rng",
     "lib",
     "library_path",
     "recompute_pixel_deltas",
     "rng_state_bytes",
     "save_image",
+    "scatter_workspace_bytes",
     "set_grayscale_pixels",
     "shard_subsequences",
 ]

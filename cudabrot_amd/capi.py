@@ -136,7 +136,9 @@ def _load():
         "cb_recompute_pixel_deltas": (i32, [dims_p, C.POINTER(C.c_char_p)]),
         "cb_rng_state_bytes": (C.c_size_t, [u32]),
         "cb_initialize_rng": (i32, [u64, u64, u32, vp, vp]),
-        "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp]),
+        "cb_scatter_workspace_bytes": (C.c_size_t, [dims_p, u32, u32]),
+        "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp, C.c_size_t, vp]),
+        "cb_flush_scatter": (i32, [dims_p, vp, u32, vp, C.c_size_t, vp]),
         "cb_renderer_create": (i32, [C.POINTER(vp), i32, dims_p, it_p, u64, u64, u32]),
         "cb_renderer_render_passes": (i32, [vp, u32, i32]),
         "cb_renderer_read_histogram": (i32, [vp, vp]),
@@ -157,7 +159,8 @@ def _load():
 lib = _load()
 EXPORTED_SYMBOLS = (
     "cb_abi_version cb_error_string cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
-    "cb_draw_buddhabrot cb_renderer_create cb_renderer_render_passes cb_renderer_read_histogram "
+    "cb_scatter_workspace_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create cb_renderer_render_passes "
+    "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image"
 ).split()
@@ -188,14 +191,27 @@ def initialize_rng(seed, first_subsequence, n_threads, d_states, stream=0):
     _check(lib.cb_initialize_rng(seed, first_subsequence, n_threads, d_states, stream), "cb_initialize_rng")
 
 
+def scatter_workspace_bytes(dims, n_threads, samples_per_thread):
+    """Suggested scatter-workspace size for launches of this shape (0: the canvas cannot use one)."""
+    return int(lib.cb_scatter_workspace_bytes(C.byref(dims), n_threads, samples_per_thread))
+
+
 def draw_buddhabrot(dims, d_hist, iterations, d_states, n_threads, samples_per_thread, d_counters=0,
-                    kernel_variant=CB_KERNEL_DEFAULT, stream=0):
-    """DrawBuddhabrot (cudabrot.cu:379-414,485-486) on caller-owned device memory; asynchronous."""
+                    kernel_variant=CB_KERNEL_DEFAULT, stream=0, d_workspace=0, workspace_bytes=0):
+    """DrawBuddhabrot (cudabrot.cu:379-414,485-486) on caller-owned device memory; asynchronous.
+    With a workspace the increments go through the deferred tile-binned scatter, else direct atomics."""
     _check(
         lib.cb_draw_buddhabrot(C.byref(dims), d_hist, C.byref(iterations), d_states, n_threads,
-                               samples_per_thread, d_counters, kernel_variant, stream),
+                               samples_per_thread, d_counters, kernel_variant, d_workspace, workspace_bytes,
+                               stream),
         "cb_draw_buddhabrot",
     )
+
+
+def flush_scatter(dims, d_hist, n_threads, d_workspace, workspace_bytes, stream=0):
+    """Adds the pixel stream a draw_buddhabrot call deferred into the workspace to the histogram."""
+    _check(lib.cb_flush_scatter(C.byref(dims), d_hist, n_threads, d_workspace, workspace_bytes, stream),
+           "cb_flush_scatter")
 
 
 class Renderer:

@@ -58,7 +58,8 @@ bool exact_reciprocal(double delta, double *inv) {
 
 cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_control *it,
                        cb_pixel *d_hist, void *d_states, uint32_t n_threads,
-                       uint32_t samples_per_thread, cb_counters *d_counters) {
+                       uint32_t samples_per_thread, cb_counters *d_counters, void *d_workspace,
+                       size_t workspace_bytes) {
   cb::DrawArgs a;
   memset(&a, 0, sizeof(a));
   a.min_real = dims->min_real;
@@ -79,8 +80,15 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.hist = reinterpret_cast<unsigned long long *>(d_hist);
   a.states = reinterpret_cast<uint32_t *>(d_states);
   a.counters = d_counters;
+  a.bin = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
+                              cb::draw_wave_count(n_threads));
   return a;
 }
+
+// Stream entries a launch is expected to produce: visited in-canvas points per sample are 0.4 (max_iter
+// 100) to 1.7 (max_iter 20000) on the full canvas; anything beyond the estimate falls back to atomics.
+constexpr double kEntriesPerSample = 2.5;
+constexpr uint32_t kRendererPassesPerLaunch = 64;
 
 }  // namespace
 
@@ -92,6 +100,9 @@ struct cb_renderer {
   cb_pixel *d_hist;
   uint32_t *d_states;
   cb_counters *d_counters;
+  void *d_workspace;       // scatter workspace, allocated on first use
+  size_t workspace_bytes;
+  int workspace_tried;
   hipStream_t stream;
 };
 
@@ -139,14 +150,29 @@ int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_thre
                                    reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
+                                  uint32_t samples_per_thread) {
+  if (!dims || dims->w <= 0 || dims->h <= 0 || dims->w > 65536 || dims->h > 65536) return 0;
+  const unsigned long long tiles = (unsigned long long) ((dims->w + cb::kTileSize - 1) / cb::kTileSize) *
+                                   (unsigned long long) ((dims->h + cb::kTileSize - 1) / cb::kTileSize);
+  if (tiles > cb::kMaxTiles || n_threads == 0 || samples_per_thread == 0) return 0;
+  const uint32_t n_waves = cb::draw_wave_count(n_threads);
+  const double entries = (double) n_threads * (double) samples_per_thread * kEntriesPerSample;
+  double per_wave = entries / n_waves;
+  if (per_wave < 2.0 * cb::kMinRegionEntries) per_wave = 2.0 * cb::kMinRegionEntries;
+  return cb::bin_fixed_bytes(n_waves, (uint32_t) tiles) +
+         (size_t) (per_wave * n_waves) * cb::kBinBytesPerEntry + 4096;
+}
+
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
-                       void *stream) {
+                       void *d_workspace, size_t workspace_bytes, void *stream) {
   if (!dims || !iterations || !d_hist || !d_states) return (int) hipErrorInvalidValue;
   if (dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
-  const cb::DrawArgs a =
-      make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread, d_counters);
+  if (kernel_variant == CB_KERNEL_SIMPLE) d_workspace = nullptr;  // the baseline kernel always uses atomics
+  const cb::DrawArgs a = make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread,
+                                   d_counters, d_workspace, workspace_bytes);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (kernel_variant) {
     case CB_KERNEL_DEFAULT:
@@ -158,6 +184,16 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
     default:
       return (int) hipErrorInvalidValue;
   }
+}
+
+int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32_t n_threads,
+                     void *d_workspace, size_t workspace_bytes, void *stream) {
+  if (!dims || !d_hist || dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
+  // the carve is a pure function of these arguments, so it is the one the draw call used
+  const cb::BinLayout b = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
+                                              cb::draw_wave_count(n_threads));
+  return (int) cb::launch_binned_scatter(b, reinterpret_cast<unsigned long long *>(d_hist), dims->w,
+                                         dims->h, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
@@ -196,14 +232,36 @@ int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimension
 int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant) {
   if (!r) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));
-  // 50 samples per thread per reference pass (cudabrot.cu:34,390); keep each launch below 2^31.
-  const uint32_t max_passes_per_launch = 0x7fffffffu / CB_SAMPLES_PER_THREAD;
+  // 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
+  const uint32_t max_passes_per_launch = kRendererPassesPerLaunch;
+  if (!r->workspace_tried && kernel_variant != CB_KERNEL_SIMPLE &&
+      getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
+    // scatter workspace for the largest launch this call makes; on any failure: direct atomics
+    r->workspace_tried = 1;
+    size_t want = cb_scatter_workspace_bytes(&r->dims, r->n_threads,
+                                             max_passes_per_launch * CB_SAMPLES_PER_THREAD);
+    size_t free_b = 0, total_b = 0;
+    if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      if (want > free_b / 2) want = free_b / 2;
+      if (hipMalloc(&r->d_workspace, want) == hipSuccess) {
+        r->workspace_bytes = want;
+      } else {
+        (void) hipGetLastError();
+        r->d_workspace = nullptr;
+      }
+    }
+  }
   while (passes > 0) {
     const uint32_t now = passes < max_passes_per_launch ? passes : max_passes_per_launch;
     int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
                                 now * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
-                                r->stream);
+                                r->d_workspace, r->workspace_bytes, r->stream);
     if (rc) return rc;
+    if (r->d_workspace && kernel_variant != CB_KERNEL_SIMPLE) {
+      rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace, r->workspace_bytes,
+                            r->stream);
+      if (rc) return rc;
+    }
     passes -= now;
   }
   return (int) hipStreamSynchronize(r->stream);  // cudabrot.cu:487
@@ -242,6 +300,7 @@ void cb_renderer_destroy(cb_renderer *r) {
   (void) hipFree(r->d_hist);
   (void) hipFree(r->d_states);
   (void) hipFree(r->d_counters);
+  (void) hipFree(r->d_workspace);
   if (r->stream) (void) hipStreamDestroy(r->stream);
   delete r;
 }

@@ -88,22 +88,32 @@ struct Canvas {
 // IncrementPixelCounter, cudabrot.cu:302-314, with the += made a device-scope atomic (the
 // reference's plain += loses updates under races) and 64-bit indexing.  Returns
 // true if a counter was incremented.
-__device__ __forceinline__ bool increment_pixel_counter(double real, double imag,
-                                                        unsigned long long *data, const Canvas &c) {
+// The pixel a point falls on: true and (row, col) if it is on the canvas.
+__device__ __forceinline__ bool pixel_of(double real, double imag, const Canvas &c, int &row,
+                                         int &col) {
   if ((real < c.min_real) || (imag < c.min_imag)) return false;
   const double fx = real - c.min_real;
   const double fy = imag - c.min_imag;
   // (int) of a double: v_cvt_i32_f64 saturates where x86 yields INT_MIN; both fail the bounds test.
-  const int col = c.pow2_real ? (int) (fx * c.inv_delta_real) : (int) (fx / c.delta_real);
-  const int row = c.pow2_imag ? (int) (fy * c.inv_delta_imag) : (int) (fy / c.delta_imag);
-  if ((row >= 0) && (row < c.h) && (col >= 0) && (col < c.w)) {
-    unsigned long long *p = data + ((unsigned long long) row * (unsigned long long) c.w +
-                                    (unsigned long long) col);
-    // result unused -> no-return global_atomic_add_x2, agent scope
-    __hip_atomic_fetch_add(p, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return true;
-  }
-  return false;
+  col = c.pow2_real ? (int) (fx * c.inv_delta_real) : (int) (fx / c.delta_real);
+  row = c.pow2_imag ? (int) (fy * c.inv_delta_imag) : (int) (fy / c.delta_imag);
+  return (row >= 0) && (row < c.h) && (col >= 0) && (col < c.w);
+}
+
+__device__ __forceinline__ void add_to_pixel(unsigned long long *data, const Canvas &c, int row,
+                                             int col, unsigned long long n) {
+  unsigned long long *p =
+      data + ((unsigned long long) row * (unsigned long long) c.w + (unsigned long long) col);
+  // result unused -> no-return global_atomic_add_x2, agent scope
+  __hip_atomic_fetch_add(p, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool increment_pixel_counter(double real, double imag,
+                                                        unsigned long long *data, const Canvas &c) {
+  int row, col;
+  if (!pixel_of(real, imag, c, row, col)) return false;
+  add_to_pixel(data, c, row, col, 1ull);
+  return true;
 }
 
 // Lane index inside the wave and prefix population count of a 64-bit lane mask.

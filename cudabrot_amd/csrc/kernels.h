@@ -17,6 +17,45 @@ void build_sequence_jump_matrices(uint32_t *out);
 // Host: seeded XORWOW state before any jump (rocrand_xorwow.h:104-123): x[0..4], d.
 void seed_state(uint64_t seed, uint32_t x[5], uint32_t *d);
 
+// ---- deferred, tile-binned scatter (scatter.hip) ------------------------------------------------
+//
+// Random u64 atomics run at ~24 G/s on MI355X whatever the schedule (one 64-byte memory-side request
+// each), which caps every configuration of this path.  With a workspace, the REPLAY stage therefore
+// does not touch the histogram: each wave appends the visited pixels as packed (row << 16 | col)
+// words to its own region of a stream in HBM (coalesced stores).  After the draw kernel the stream is
+// partitioned by 128x128-pixel tile with a counting sort (count per (wave, tile) -> exclusive scan
+// -> scatter of 14-bit in-tile offsets, no atomics, deterministic), and one workgroup per tile
+// accumulates its bucket in an LDS histogram and adds the tile to the u64 histogram with coalesced
+// atomics: one 64-byte request per 8 pixels per launch instead of one per increment.
+constexpr int kTileShift = 7;
+constexpr int kTileSize = 1 << kTileShift;          // 128 x 128 pixels
+constexpr int kTilePixels = kTileSize * kTileSize;  // 16384 u32 counters = 64 KiB of LDS
+constexpr uint32_t kMaxTiles = 4096;                // canvases up to 8192 x 8192
+constexpr uint32_t kMinRegionEntries = 4096;        // below this per wave the workspace is not used
+
+struct BinLayout {
+  uint32_t enabled;     // 0: REPLAY adds to the histogram directly
+  uint32_t n_waves;     // regions in the stream (= waves of the draw kernel)
+  uint32_t cap;         // entries per region (multiple of 4)
+  uint32_t n_tiles;     // tiles_x * tiles_y
+  uint32_t tiles_x;
+  uint32_t *wave_count;           // [n_waves]            entries written by each wave
+  uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
+  uint32_t *count;                // [n_waves][n_tiles]   counts, then exclusive prefix over waves
+  unsigned long long *tile_base;  // [n_tiles + 1]        exclusive prefix over tiles
+  uint16_t *sorted;               // [n_waves * cap]      in-tile offsets grouped by tile
+};
+
+// Fixed (entry-independent) bytes of a workspace and bytes per stream entry.
+size_t bin_fixed_bytes(uint32_t n_waves, uint32_t n_tiles);
+constexpr size_t kBinBytesPerEntry = sizeof(uint32_t) + sizeof(uint16_t);
+// Carves `bytes` at `workspace` into a BinLayout (enabled = 0 if it is too small or the canvas does
+// not qualify: more than kMaxTiles tiles or a side above 65536).
+BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves);
+// count -> scan -> scatter -> accumulate on `stream`, after the draw kernel that filled the stream.
+hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
+                                 hipStream_t stream);
+
 struct DrawArgs {
   // canvas (cudabrot.cu:46-58) + exact-reciprocal fast path
   double min_real, min_imag, delta_real, delta_imag, inv_delta_real, inv_delta_imag;
@@ -30,7 +69,13 @@ struct DrawArgs {
   unsigned long long *hist;
   uint32_t *states;  // six planes of n_threads
   cb_counters *counters;
+  BinLayout bin;
 };
+
+constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup
+inline uint32_t draw_wave_count(uint32_t n_threads) {
+  return ((n_threads + kDrawBlockThreads - 1u) / kDrawBlockThreads) * (kDrawBlockThreads / 64u);
+}
 
 hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads,
                            uint32_t *d_states, const uint32_t *d_matrices, hipStream_t stream);
@@ -38,7 +83,7 @@ hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream);
 hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
 
 // Steps per chunk of the long-iterate stage; head_steps is chosen so that
-// (max_iter - head_steps) % kChunk == 0.
+// (min_iter - head_steps) % kChunk == 0 whenever min_iter lies beyond the head.
 constexpr int kChunk = 16;
 int choose_head_steps(int max_iter, int min_iter);
 

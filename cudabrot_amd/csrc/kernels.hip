@@ -344,10 +344,18 @@ __device__ __forceinline__ bool lane_in(unsigned long long mask) {
   return (mask >> lane_id()) & 1ull;
 }
 
-template <bool kTimed>
+template <bool kTimed, bool kBinned>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs a) {
+  static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
   __shared__ WaveQueues queues[kWavesPerBlock];
   WaveQueues &q = queues[threadIdx.x >> 6];
+
+  // kBinned: this wave's region of the pixel stream (kernels.h, BinLayout)
+  const uint32_t wave_id =
+      __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  uint32_t *const region = kBinned ? a.bin.stream + (size_t) wave_id * a.bin.cap : nullptr;
+  const uint32_t region_cap = kBinned ? a.bin.cap : 0u;
+  uint32_t region_fill = 0;
 
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = tid < a.n_threads;
@@ -422,9 +430,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
           if (act_mask == 0ull) break;
           n_replay += (unsigned long long) __popcll(act_mask);
           bool done = false, hit = false;
+          // kBinned: the visited pixels go to this wave's stream region (compacted, coalesced
+          // stores); a full region falls back to direct atomics, so results never depend on it.
+          const bool to_stream = kBinned && (region_fill + 64u <= region_cap);
+          int row = 0, col = 0;
           if (p_act) {
             const double m = mandel_step(p_cr, p_ci, p_r, p_i);       // cudabrot.cu:357-359
-            hit = increment_pixel_counter(p_r, p_i, a.hist, cv);      // cudabrot.cu:360
+            hit = pixel_of(p_r, p_i, cv, row, col);                   // cudabrot.cu:308-311
+            if (hit && !to_stream) add_to_pixel(a.hist, cv, row, col, 1ull);  // cudabrot.cu:312
             p_steps++;
             done = m > 4.0;                                           // cudabrot.cu:363
             if (!done && p_steps > max_iter) {
@@ -434,7 +447,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
             }
             if (done) p_act = false;
           }
-          n_incr += (unsigned long long) __popcll(__ballot(hit));
+          const unsigned long long hit_mask = __ballot(hit);
+          n_incr += (unsigned long long) __popcll(hit_mask);
+          if (kBinned && to_stream && hit_mask != 0ull) {
+            if (hit) {
+              region[region_fill + (uint32_t) mask_prefix(hit_mask)] =
+                  ((uint32_t) row << 16) | (uint32_t) col;
+            }
+            region_fill += (uint32_t) __popcll(hit_mask);
+          }
           if (__ballot(done) != 0ull && q2_count > 0) break;
         }
       }
@@ -567,6 +588,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
   }
 
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
+  if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
     const unsigned long long n_samples =
@@ -592,10 +614,16 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
-  if (timed) {
-    hipLaunchKernelGGL(draw_wave_kernel<true>, dim3(blocks), dim3(threads), 0, stream, a);
+  const bool binned = a.bin.enabled != 0u;
+  if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
+  if (timed && binned) {
+    hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else if (timed) {
+    hipLaunchKernelGGL((draw_wave_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else if (binned) {
+    hipLaunchKernelGGL((draw_wave_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(draw_wave_kernel<false>, dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wave_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
   }
   return hipGetLastError();
 }

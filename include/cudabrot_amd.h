@@ -93,15 +93,33 @@ size_t cb_rng_state_bytes(uint32_t n_threads);
 int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
                       void *stream);
 
+/* Suggested size of the scatter workspace of cb_draw_buddhabrot for launches of this shape (0 if the
+ * canvas cannot use one: more than 4096 tiles of 128x128 pixels, or a side above 65536).  Any size
+ * works: increments that do not fit are added with direct atomics, the result is the same. */
+size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
+                                  uint32_t samples_per_thread);
+
 /* DrawBuddhabrot<<<block_count, block_size>>>(dimensions, data, iterations, states)
  * (cudabrot.cu:379-414,485-486) for n_threads threads, samples_per_thread samples each (the
  * reference: 50 per launch; k reference passes in one launch = 50*k).  Adds to d_hist (w*h
- * cb_pixel, row-major, row 0 = min_imag) with device-scope atomics, advances d_states, and adds to
- * d_counters (may be NULL). */
+ * cb_pixel, row-major, row 0 = min_imag), advances d_states, and adds to d_counters (may be NULL).
+ * Without a workspace (d_workspace NULL) every increment is a device-scope atomic on d_hist (the
+ * reference's += of cudabrot.cu:312, made atomic) and d_hist is complete when the launch is.
+ * With one, the increments that fit are DEFERRED: the kernel streams the visited pixels into the
+ * workspace and the caller must then run cb_flush_scatter on the same workspace (stream-ordered
+ * after this call) before it reads d_hist or reuses the workspace; what does not fit is added
+ * atomically at once, so the sum is the same for any workspace size. */
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
-                       void *stream);
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Second half of the scatter: partitions the pixel stream a cb_draw_buddhabrot call left in
+ * d_workspace by 128x128-pixel tile (counting sort) and adds every tile to d_hist from an LDS
+ * histogram with coalesced atomics.  Same dims, n_threads, d_workspace and workspace_bytes as that
+ * call.  A no-op for a workspace the draw call could not use. */
+int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32_t n_threads,
+                     void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---- Renderer: SetupCUDA + RenderImage + the -s buffer, as an owned object ---------------------- */
 

@@ -156,6 +156,69 @@ def test_write_histogram_then_render_adds(cb, oracle):
     assert np.array_equal(got, base + cpu)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(w=4096, h=4096, max_iter=2000, min_iter=20, threads=20000, passes=1),
+    dict(w=1000, h=1000, max_iter=300, min_iter=20, threads=8192, passes=3),
+    dict(w=333, h=77, max_iter=500, min_iter=0, threads=1000, passes=4, box=(-1.7, 0.9, -0.3, 1.1)),
+], ids=["c2shape", "nonpow2", "odd_canvas"])
+def test_direct_atomics_mode_equals_binned_mode(cb, oracle, cfg, monkeypatch):
+    """Without a scatter workspace every increment is a device-scope atomic; same histogram."""
+    box = cfg.get("box", BOX)
+    monkeypatch.setenv("CUDABROT_AMD_NO_WORKSPACE", "1")
+    direct = gpu_render(cb, cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    monkeypatch.delenv("CUDABROT_AMD_NO_WORKSPACE")
+    binned = gpu_render(cb, cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    cpu = oracle.render(cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    assert_same(direct, cpu)
+    assert_same(binned, cpu)
+
+
+def _torch_render(cb, w, h, max_iter, min_iter, t, passes, workspace_bytes, box=BOX):
+    import torch
+
+    dev = torch.device("cuda:0")
+    dims = cb.FractalDimensions.make(w, h, box[0], box[1], box[2], box[3])
+    it = cb.IterationControl(max_iter, min_iter)
+    states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    counters = torch.zeros(14, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(workspace_bytes, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
+    for _ in range(passes):
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), t, 50, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, ws.data_ptr() if workspace_bytes else 0, workspace_bytes)
+        if workspace_bytes:
+            cb.flush_scatter(dims, hist.data_ptr(), t, ws.data_ptr(), workspace_bytes, stream)
+    torch.cuda.synchronize()
+    c = counters.cpu().numpy().view(np.uint64)
+    cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in c)))
+    return hist.cpu().numpy().view(np.uint64).reshape(h, w), cnt
+
+
+@pytest.mark.parametrize("workspace", ["suggested", "tiny", "one_region_short", "none"])
+def test_scatter_workspace_sizes(cb, oracle, workspace):
+    """Any workspace size gives the same histogram: what does not fit the stream falls back to atomics."""
+    w, h, t, passes = 700, 500, 8192, 3
+    dims = cb.FractalDimensions.make(w, h)
+    suggested = cb.scatter_workspace_bytes(dims, t, 50)
+    assert suggested > 0
+    size = {"suggested": suggested, "tiny": 4096, "one_region_short": suggested // 3, "none": 0}[workspace]
+    got = _torch_render(cb, w, h, 600, 20, t, passes, size)
+    cpu = oracle.render(w, h, 600, 20, t, passes)
+    assert_same(got, cpu)
+
+
+def test_canvas_that_cannot_use_the_workspace(cb, oracle):
+    """A side above 65536 does not fit the packed (row, col) stream word: direct atomics."""
+    w, h, t = 66000, 6, 4096
+    dims = cb.FractalDimensions.make(w, h)
+    assert cb.scatter_workspace_bytes(dims, t, 50) == 0
+    got = _torch_render(cb, w, h, 200, 20, t, 2, 1 << 20)
+    cpu = oracle.render(w, h, 200, 20, t, 2)
+    assert_same(got, cpu)
+
+
 def test_low_level_entry_points_on_torch_memory(cb, oracle):
     """cb_initialize_rng / cb_draw_buddhabrot on caller-owned device memory (torch as the allocator)."""
     import torch
