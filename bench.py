@@ -144,7 +144,7 @@ def main():
     first, threads = shard_subsequences(rank, world, THREADS)
     hist = torch.zeros(W * H, dtype=torch.int64, device=dev)              # u64 counters
     states = torch.empty(cb.rng_state_bytes(threads), dtype=torch.uint8, device=dev)
-    counters = torch.zeros(14, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, first, threads, states.data_ptr(), stream)
     samples_per_thread = SAMPLES_PER_PASS * PASSES_PER_STEP

@@ -79,12 +79,15 @@ class Counters(C.Structure):
             "iterate_steps",
             "replay_steps",
             "increments",
-            "reserved",
+            "skipped_steps",
             "status",
             "cycles_head",
             "cycles_long",
             "cycles_replay",
             "cycles_total",
+            "rt_not_first_start",
+            "rt_last_end",
+            "rt_wave_life_sum",
         )
     ]
 

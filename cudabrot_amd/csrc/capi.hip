@@ -1,6 +1,7 @@
 // capi.hip -- implementation of include/cudabrot_amd.h (the C ABI).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -56,6 +57,10 @@ bool exact_reciprocal(double delta, double *inv) {
   return true;
 }
 
+// Diagnostic only (CUDABROT_AMD_WAVE_DUMP=<file> with the timed kernel variant): per-wave records of
+// the last launch, see DrawArgs::wave_dump.
+unsigned long long *g_wave_dump = nullptr;
+
 cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_control *it,
                        cb_pixel *d_hist, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, void *d_workspace,
@@ -82,6 +87,7 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.counters = d_counters;
   a.bin = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
                               cb::draw_wave_count(n_threads));
+  a.wave_dump = g_wave_dump;
   return a;
 }
 
@@ -234,6 +240,12 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
   CB_TRY(hipSetDevice(r->device));
   // 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
   const uint32_t max_passes_per_launch = kRendererPassesPerLaunch;
+  if (kernel_variant == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") && !g_wave_dump) {
+    const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
+    if (hipMalloc(&g_wave_dump, bytes) != hipSuccess || hipMemset(g_wave_dump, 0, bytes) != hipSuccess) {
+      g_wave_dump = nullptr;
+    }
+  }
   if (!r->workspace_tried && kernel_variant != CB_KERNEL_SIMPLE &&
       getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
     // scatter workspace for the largest launch this call makes; on any failure: direct atomics
@@ -263,6 +275,19 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
       if (rc) return rc;
     }
     passes -= now;
+  }
+  if (g_wave_dump) {  // diagnostic: write the per-wave records of the last launch
+    (void) hipStreamSynchronize(r->stream);
+    const size_t n = (size_t) cb::draw_wave_count(r->n_threads) * 8;
+    std::vector<unsigned long long> host(n);
+    if (hipMemcpy(host.data(), g_wave_dump, n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+      if (FILE *f = fopen(getenv("CUDABROT_AMD_WAVE_DUMP"), "wb")) {
+        fwrite(host.data(), 8, n, f);
+        fclose(f);
+      }
+    }
+    (void) hipFree(g_wave_dump);
+    g_wave_dump = nullptr;
   }
   return (int) hipStreamSynchronize(r->stream);  // cudabrot.cu:487
 }

@@ -398,6 +398,7 @@ class Run {
       next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
       if (next < 1) next = 1;
       if (next > 4096) next = 4096;
+      if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
     }
     CB_CHECK(cb_renderer_read_histogram(renderer_, counts_));
     printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
@@ -415,15 +416,19 @@ class Run {
     fprintf(stderr,
             "{\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
             "\"recorded\": %llu, \"iterate_steps\": %llu, \"replay_steps\": %llu, "
-            "\"increments\": %llu, \"status\": %llu, \"cycles_head\": %llu, \"cycles_long\": %llu, "
-            "\"cycles_replay\": %llu, \"cycles_total\": %llu}\n",
+            "\"increments\": %llu, \"skipped_steps\": %llu, \"status\": %llu, \"cycles_head\": %llu, "
+            "\"cycles_long\": %llu, "
+            "\"cycles_replay\": %llu, \"cycles_total\": %llu, \"rt_span\": %llu, \"rt_wave_life_sum\": %llu}\n",
             (unsigned long long) c.samples, (unsigned long long) c.rejected,
             (unsigned long long) c.never_escaped, (unsigned long long) c.too_fast,
             (unsigned long long) c.recorded, (unsigned long long) c.iterate_steps,
             (unsigned long long) c.replay_steps, (unsigned long long) c.increments,
+            (unsigned long long) c.skipped_steps,
             (unsigned long long) c.status, (unsigned long long) c.cycles_head,
             (unsigned long long) c.cycles_long, (unsigned long long) c.cycles_replay,
-            (unsigned long long) c.cycles_total);
+            (unsigned long long) c.cycles_total,
+            (unsigned long long) (c.rt_last_end ? c.rt_last_end - ~c.rt_not_first_start : 0),
+            (unsigned long long) c.rt_wave_life_sum);
   }
 
   void save_image() {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0

@@ -41,8 +41,9 @@ struct BinLayout {
   uint32_t tiles_x;
   uint32_t *wave_count;           // [n_waves]            entries written by each wave
   uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
-  uint32_t *count;                // [n_waves][n_tiles]   counts, then exclusive prefix over waves
+  uint32_t *count;                // [n_tiles][n_waves]   counts, then exclusive prefix over waves
   unsigned long long *tile_base;  // [n_tiles + 1]        exclusive prefix over tiles
+  uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate slices
   uint16_t *sorted;               // [n_waves * cap]      in-tile offsets grouped by tile
 };
 
@@ -70,6 +71,9 @@ struct DrawArgs {
   uint32_t *states;  // six planes of n_threads
   cb_counters *counters;
   BinLayout bin;
+  // timed variant only, may be null: 8 words per wave {HW_ID, XCC_ID, start, end (100 MHz clock),
+  // cycles in HEAD, LONG, REPLAY, total}
+  unsigned long long *wave_dump;
 };
 
 constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup

@@ -13,6 +13,8 @@
 //                      in front of it).
 #include "kernels.h"
 
+#include <stdlib.h>
+
 #include "device_math.h"
 
 namespace cb {
@@ -255,7 +257,9 @@ hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream) {
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Cap = 128;   // power of two
 constexpr int kQ2Cap = 256;   // power of two
-constexpr int kQ1Low = 16;    // run HEAD rounds while fewer survivors than this are queued
+constexpr int kQ1Low = 32;    // run HEAD rounds while fewer survivors than this are queued
+constexpr int kOrbitsPerLane = 2;  // deep orbits a lane iterates side by side in the LONG stage
+constexpr uint32_t kPrioChunks = 64;  // chunks per priority level in the rotation (power of two)
 constexpr int kReplayMin = 32;   // suspend REPLAY below this many busy lanes (unless draining)
 constexpr int kReplayBurst = 8;  // replay steps between refill checks
 
@@ -279,32 +283,75 @@ struct WaveQueues {
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
   "v_cmpx_nlt_f64_e32 vcc, 4.0, %[a]\n\t"
-#define CB_STEP4 CB_STEP CB_STEP CB_STEP CB_STEP
-#define CB_STEP16 CB_STEP4 CB_STEP4 CB_STEP4 CB_STEP4
+// The LONG stage keeps TWO independent orbits (A and B) per lane and interleaves them instruction by
+// instruction: the step is a chain of ~6 dependent fp64 operations, and a SIMD whose waves finish
+// one after the other (VALU issue goes by wave age) must be able to fill the fp64 pipe from few
+// waves.  Measured with bare loops on MI355X: 4 waves x 1 orbit 59 % of fp64 issue, 4 x 2 orbits
+// 72 %, 1 x 1 32 %, 1 x 2 46 %.
+//
+// Two orbit sets cannot share one EXEC mask, so EXEC stays untouched: every lane computes every
+// step (an idle or already escaped lane computes garbage that nothing reads) and the lanes still
+// iterating are tracked in two scalar masks, la and lb: la &= !(4.0 < |zA|^2) after each step
+// (cudabrot.cu:336).  The and for step n is issued inside step n+1, behind its first VALU
+// instructions, so that the scalar unit never waits for the compare.  cnt += popcount(la) +
+// popcount(lb) before each step keeps the exact count of iterations the reference would execute.
+// Same instruction order per orbit as CB_STEP / mandel_step.
+#define CB_STEP2                                          \
+  "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
+  "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
+  "s_and_b64 %[la], %[la], %[c0]\n\t"                     \
+  "v_add_f64 %[b0], %[ra], %[ra]\n\t"                     \
+  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
+  "v_add_f64 %[b1], %[rb], %[rb]\n\t"                     \
+  "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
+  "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
+  "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
+  "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
+  "s_add_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
+  "v_fma_f64 %[ia], %[b0], %[ia], %[cia]\n\t"             \
+  "s_add_u32 %[cnt], %[cnt], %[t1]\n\t"                   \
+  "v_fma_f64 %[ib], %[b1], %[ib], %[cib]\n\t"             \
+  "v_add_f64 %[ra], %[cra], %[a0]\n\t"                    \
+  "v_add_f64 %[rb], %[crb], %[a1]\n\t"                    \
+  "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
+  "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
+  "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
+  "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
+  "v_cmp_nlt_f64_e64 %[c0], 4.0, %[a0]\n\t"               \
+  "v_cmp_nlt_f64_e64 %[c1], 4.0, %[a1]\n\t"
+#define CB_STEP2X4 CB_STEP2 CB_STEP2 CB_STEP2 CB_STEP2
+#define CB_STEP2X16 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
 
-// kChunk steps on the lanes of `mask` (wave-uniform).  Returns the lanes that escaped; r, i of the
-// other lanes advance by kChunk iterations; lane_steps receives the executed lane-steps.
-__device__ __forceinline__ unsigned long long iterate_chunk(unsigned long long mask, double cr,
-                                                            double ci, double &r, double &i,
-                                                            uint32_t &lane_steps) {
-  static_assert(kChunk == 16, "CB_STEP16 is unrolled for 16 steps");
-  unsigned long long save, escaped;
-  uint32_t cnt, tmp;
-  double a, b;
+struct Orbit {
+  double cr, ci, r, i;
+};
+
+// kChunk steps on orbit A of the lanes in mask_a and on orbit B of the lanes in mask_b (both
+// wave-uniform; called with EXEC = all 64 lanes).  esc_a / esc_b receive the lanes whose orbit
+// escaped; the other lanes of the masks advance by kChunk iterations; lane_steps receives the
+// executed lane-steps.  Orbits of lanes outside the masks are clobbered.
+__device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsigned long long mask_b,
+                                               Orbit &oa, Orbit &ob, unsigned long long &esc_a,
+                                               unsigned long long &esc_b, uint32_t &lane_steps) {
+  static_assert(kChunk == 16, "CB_STEP2X16 is unrolled for 16 steps");
+  unsigned long long la = mask_a, lb = mask_b, c0, c1;
+  uint32_t cnt, t0, t1;
+  double a0, a1, b0, b1;
   asm volatile(
-      "s_mov_b64 %[save], exec\n\t"
       "s_mov_b32 %[cnt], 0\n\t"
-      "s_mov_b64 exec, %[mask]\n\t"
-      CB_STEP16
-      "s_andn2_b64 %[esc], %[mask], exec\n\t"
-      "s_mov_b64 exec, %[save]\n\t"
-      "s_nop 4\n\t"
-      : [r] "+v"(r), [i] "+v"(i), [a] "=&v"(a), [b] "=&v"(b), [save] "=&s"(save),
-        [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp)
-      : [mask] "s"(mask), [cr] "v"(cr), [ci] "v"(ci)
-      : "vcc", "scc");
+      "s_mov_b64 %[c0], -1\n\t"
+      "s_mov_b64 %[c1], -1\n\t"
+      CB_STEP2X16
+      "s_and_b64 %[la], %[la], %[c0]\n\t"
+      "s_and_b64 %[lb], %[lb], %[c1]\n\t"
+      : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [la] "+s"(la),
+        [lb] "+s"(lb), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+        [c0] "=&s"(c0), [c1] "=&s"(c1), [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci)
+      : "scc");
+  esc_a = mask_a & ~la;
+  esc_b = mask_b & ~lb;
   lane_steps = cnt;
-  return escaped;
 }
 
 // n steps (wave-uniform run-time count) on the lanes of `mask`, leaving early once every lane has
@@ -381,10 +428,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
                      n_replay = 0, n_incr = 0, status = 0;
   unsigned long long t_head = 0, t_long = 0, t_replay = 0;
   const unsigned long long t_start = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_start = kTimed ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-  // LONG lane state
-  double l_cr = 0, l_ci = 0, l_r = 0, l_i = 0;
-  int l_rem = 0;  // iterations left before max_iter; 0 = idle
+  // wave slot on its SIMD (HW_REG_HW_ID bits 3:0) and chunks done, for the priority rotation
+  const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));
+  uint32_t long_chunks = 0;
+  // LONG lane state: two orbits per lane (see CB_STEP2)
+  Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
+  unsigned long long skipped_steps = 0;  // per lane: iterations the periodicity check made unnecessary
+  int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
   // REPLAY lane state
   double p_cr = 0, p_ci = 0, p_r = 0, p_i = 0;
   bool p_act = false;
@@ -392,7 +445,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
 
   for (;;) {
     const bool input_done = (samples_left == 0);
-    const bool l_any = __ballot(l_rem > 0) != 0ull;
+    const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0) != 0ull;
     const bool draining = input_done && (q1_count == 0) && !l_any;
     const int n_replaying = __popcll(__ballot(p_act));
 
@@ -523,62 +576,115 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
     // ---------------------------------------------------------------- LONG
     const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
     for (;;) {
-      {  // refill idle lanes from Q1
-        const unsigned long long idle_mask = __ballot(l_rem == 0);
+      // Even progress for the waves of a SIMD.  VALU issue goes by priority, then by wave age, so
+      // with equal priorities the oldest wave races ahead and the youngest is left to finish alone,
+      // where one wave cannot fill the fp64 pipe (measured: the 4 waves of a SIMD ended at 31 / 40 /
+      // 53 / 65 ms).  Each wave therefore walks through the four priority levels as it progresses,
+      // offset by its wave slot: over one round of 4 * kPrioChunks chunks every wave has had every
+      // level for the same amount of work.
+      if ((long_chunks & (kPrioChunks - 1u)) == 0u) {
+        switch ((wave_slot + long_chunks / kPrioChunks) & 3u) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+      }
+      ++long_chunks;
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {  // refill idle orbit slots from Q1
+        const unsigned long long idle_mask = __ballot(l_rem[o] == 0);
         const int n_idle = __popcll(idle_mask);
         const int n = n_idle < q1_count ? n_idle : q1_count;
         if (n > 0) {
           const int rank = mask_prefix(idle_mask);
-          if (l_rem == 0 && rank < n) {
+          if (l_rem[o] == 0 && rank < n) {
             const int slot = (q1_head + rank) & (kQ1Cap - 1);
-            l_cr = q.q1_cr[slot];
-            l_ci = q.q1_ci[slot];
-            l_r = q.q1_r[slot];
-            l_i = q.q1_i[slot];
-            l_rem = long_steps;
+            lo[o].cr = q.q1_cr[slot];
+            lo[o].ci = q.q1_ci[slot];
+            lo[o].r = q.q1_r[slot];
+            lo[o].i = q.q1_i[slot];
+            l_rem[o] = long_steps;
+            seen_r[o] = lo[o].r;  // periodicity check: first saved point = the entry point
+            seen_i[o] = lo[o].i;
           }
           q1_head = (q1_head + n) & (kQ1Cap - 1);
           q1_count -= n;
         }
       }
-      const unsigned long long full_mask = __ballot(l_rem >= kChunk);
-      const unsigned long long tail_mask = __ballot(l_rem > 0 && l_rem < kChunk);
-      if ((full_mask | tail_mask) == 0ull) break;
+      unsigned long long full_mask[kOrbitsPerLane], tail_mask[kOrbitsPerLane], esc[kOrbitsPerLane];
+      unsigned long long any_mask = 0ull;
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {
+        full_mask[o] = __ballot(l_rem[o] >= kChunk);
+        tail_mask[o] = __ballot(l_rem[o] > 0 && l_rem[o] < kChunk);
+        esc[o] = 0ull;
+        any_mask |= full_mask[o] | tail_mask[o];
+      }
+      if (any_mask == 0ull) break;
 
-      unsigned long long esc = 0ull;
       uint32_t steps = 0;
-      if (tail_mask != 0ull) {  // last, shorter chunk of these lanes: exactly tail_steps iterations
-        esc = iterate_steps(tail_mask, (uint32_t) tail_steps, l_cr, l_ci, l_r, l_i, steps);
-        n_iterate += steps;
-        n_never += (unsigned long long) __popcll(tail_mask & ~esc);
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {
+        if (tail_mask[o] != 0ull) {  // last, shorter chunk of these orbits: exactly tail_steps iterations
+          esc[o] = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o].cr, lo[o].ci, lo[o].r,
+                                 lo[o].i, steps);
+          n_iterate += steps;
+          n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc[o]);
+        }
       }
-      if (full_mask != 0ull) {
-        esc |= iterate_chunk(full_mask, l_cr, l_ci, l_r, l_i, steps);
+      if ((full_mask[0] | full_mask[1]) != 0ull) {
+        unsigned long long e0, e1;
+        iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], e0, e1, steps);
+        esc[0] |= e0;
+        esc[1] |= e1;
         n_iterate += steps;
       }
-      // Bookkeeping.  A lane's chunk covered escape indices [k_lo, k_lo + chunk length) with
+      // Bookkeeping.  An orbit's chunk covered escape indices [k_lo, k_lo + chunk length) with
       // k_lo = max_iter - l_rem; min_iter - head_steps is a multiple of kChunk, so the whole chunk
       // is on one side of min_iter (cudabrot.cu:407-408).
-      const bool escaped = lane_in(esc);
-      const bool in_full = lane_in(full_mask);
-      const bool in_tail = lane_in(tail_mask);
-      const bool push = escaped && (max_iter - l_rem >= min_iter);
-      n_too_fast += (unsigned long long) __popcll(__ballot(escaped && !push));
-      if (escaped || in_tail) {
-        l_rem = 0;
-      } else if (in_full) {
-        l_rem -= kChunk;
-      }
-      n_never += (unsigned long long) __popcll(__ballot(in_full && !escaped && l_rem == 0));
-      const unsigned long long push_mask = __ballot(push);
-      if (push_mask != 0ull) {
-        if (push) {
-          const int slot = (q2_head + q2_count + mask_prefix(push_mask)) & (kQ2Cap - 1);
-          q.q2_cr[slot] = l_cr;
-          q.q2_ci[slot] = l_ci;
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {
+        const bool escaped = lane_in(esc[o]);
+        const bool in_full = lane_in(full_mask[o]);
+        const bool in_tail = lane_in(tail_mask[o]);
+        const bool push = escaped && (max_iter - l_rem[o] >= min_iter);
+        n_too_fast += (unsigned long long) __popcll(__ballot(escaped && !push));
+        if (escaped || in_tail) {
+          l_rem[o] = 0;
+        } else if (in_full) {
+          l_rem[o] -= kChunk;
+          // Exact-periodicity early-out.  If z is bit for bit a value this orbit
+          // held at an earlier chunk boundary, the (deterministic) orbit repeats that stretch for
+          // ever and every point of the stretch passed the escape test: the sample can never
+          // escape, so IterateMandelbrot would return max_iterations (cudabrot.cu:339) -- the same
+          // outcome, without executing the remaining iterations.  Brent's scheme at chunk
+          // granularity: compare with one saved point, re-save when the chunk count is a power
+          // of two; a cycle of period p is found at most 16 p iterations after it has begun.
+          const bool periodic = (__double_as_longlong(lo[o].r) == __double_as_longlong(seen_r[o])) &&
+                                (__double_as_longlong(lo[o].i) == __double_as_longlong(seen_i[o]));
+          if (periodic && l_rem[o] > 0) {
+            skipped_steps += (unsigned long long) l_rem[o];
+            l_rem[o] = 0;  // counted below with the orbits that ran to max_iter
+          } else {
+            const int chunks_done = (long_steps - l_rem[o]) / kChunk;
+            if ((chunks_done & (chunks_done - 1)) == 0) {
+              seen_r[o] = lo[o].r;
+              seen_i[o] = lo[o].i;
+            }
+          }
         }
-        q2_count += __popcll(push_mask);
-        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        n_never += (unsigned long long) __popcll(__ballot(in_full && !escaped && l_rem[o] == 0));
+        const unsigned long long push_mask = __ballot(push);
+        if (push_mask != 0ull) {
+          if (push) {
+            const int slot = (q2_head + q2_count + mask_prefix(push_mask)) & (kQ2Cap - 1);
+            q.q2_cr[slot] = lo[o].cr;
+            q.q2_ci[slot] = lo[o].ci;
+          }
+          q2_count += __popcll(push_mask);
+          if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        }
       }
       // leave the stage when another one has work to do
       if (q2_count + __popcll(__ballot(p_act)) >= 64) break;      // REPLAY can fill every lane
@@ -589,12 +695,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
 
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
   if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
+  const unsigned long long skipped_total = wave_sum(skipped_steps);
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
     const unsigned long long n_samples =
         (unsigned long long) __popcll(valid_mask) * (unsigned long long) a.samples_per_thread;
     const unsigned long long v[9] = {n_samples, n_rejected, n_never,  n_too_fast, n_recorded,
-                                     n_iterate, n_replay,   n_incr,   0ull};
+                                     n_iterate + skipped_total, n_replay, n_incr, skipped_total};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -606,6 +713,23 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
       __hip_atomic_fetch_add(c + 11, t_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(c + 12, t_replay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(c + 13, t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // wave residency on the 100 MHz constant clock: first start (kept as max of ~start), last end,
+      // and the sum of wave lifetimes
+      const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+      __hip_atomic_fetch_max(c + 14, ~rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(c + 15, rt_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 16, rt_end - rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.wave_dump) {
+        unsigned long long *d = a.wave_dump + (size_t) wave_id * 8;
+        d[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all bits
+        d[1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+        d[2] = rt_start;
+        d[3] = rt_end;
+        d[4] = t_head;
+        d[5] = t_long;
+        d[6] = t_replay;
+        d[7] = t_all;
+      }
     }
   }
 }
@@ -616,14 +740,21 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
   const bool binned = a.bin.enabled != 0u;
   if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
+  // Unused dynamic LDS on top of the 32 KiB of queues: with 40 KiB per workgroup exactly four fit a
+  // CU (160 KiB), so the reference-sized grid (1024 workgroups) lands as 4 per CU = 4 waves per SIMD
+  // everywhere instead of 5 on some CUs and 3 on others.
+  static const int lds_pad = [] {
+    const char *e = getenv("CUDABROT_AMD_LDS_PAD");
+    return e ? atoi(e) : 8192;
+  }();
   if (timed && binned) {
-    hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), lds_pad, stream, a);
   } else if (timed) {
-    hipLaunchKernelGGL((draw_wave_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wave_kernel<true, false>), dim3(blocks), dim3(threads), lds_pad, stream, a);
   } else if (binned) {
-    hipLaunchKernelGGL((draw_wave_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wave_kernel<false, true>), dim3(blocks), dim3(threads), lds_pad, stream, a);
   } else {
-    hipLaunchKernelGGL((draw_wave_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wave_kernel<false, false>), dim3(blocks), dim3(threads), lds_pad, stream, a);
   }
   return hipGetLastError();
 }

@@ -2,20 +2,23 @@
 //
 // Input: the pixel stream the REPLAY stage of draw_wave_kernel wrote -- per wave a region of packed
 // (row << 16 | col) words.  Output: the same increments added to the u64 histogram, with one
-// 64-byte memory-side request per 8 pixels of a tile instead of one per increment.
+// 64-byte memory-side request per 8 pixels of a tile slice instead of one per increment.
 //
-//   bin_count_kernel       one workgroup per wave region: LDS histogram over tiles -> count[wave][tile]
-//   bin_scan_waves_kernel  per tile: exclusive prefix over waves (in place), tile totals
-//   bin_scan_tiles_kernel  exclusive prefix over the tile totals -> tile_base[]
+//   bin_count_kernel       one workgroup per wave region: LDS histogram over tiles -> count[tile][wave]
+//   bin_scan_waves_kernel  one workgroup per tile: exclusive prefix over waves (in place), tile total
+//   bin_scan_tiles_kernel  exclusive prefix over the tile totals -> tile_base[]; and over the number
+//                          of accumulate slices per tile -> slice_base[]
 //   bin_scatter_kernel     one workgroup per wave region, chunks of 8192 entries: rank inside
 //                          (chunk, tile) by LDS atomics, sort the chunk in LDS, write each tile's run to
-//                          its place in `sorted` as 14-bit in-tile offsets (coalesced 2-byte stores)
-//   bin_accumulate_kernel  one workgroup per tile: LDS u32 histogram of the tile's bucket, then the
-//                          tile is added to the u64 histogram with coalesced device-scope atomics
+//                          its place in `sorted` as 14-bit in-tile offsets (consecutive lanes write
+//                          consecutive places of a run)
+//   bin_accumulate_kernel  one workgroup per slice (<= 65536 entries of one tile): LDS u32 histogram
+//                          of the slice, then added to the u64 histogram with coalesced device-scope
+//                          atomics.  Hot tiles are many slices, so the grid stays balanced.
 //
 // Everything is a counting sort: no global atomics before the final flush, and the bytes written are
-// the same from run to run.  All of it is HBM-streaming work (6 + 4 + 4 + 2 + 2 = 18 bytes per
-// increment end to end) that the draw kernel's fp64 loop leaves idle.
+// the same from run to run.  All of it is HBM-streaming work (4 + 4 + 4 + 2 + 2 = 16 bytes per
+// increment end to end, plus 16 KiB of flush per slice) that the draw kernel's fp64 loop leaves idle.
 #include "kernels.h"
 
 namespace cb {
@@ -25,6 +28,8 @@ namespace {
 constexpr uint32_t kScatterThreads = 512;
 constexpr uint32_t kChunkEntries = 8192;  // 16 per thread
 constexpr uint32_t kPerThread = kChunkEntries / kScatterThreads;
+constexpr uint32_t kSliceEntries = 65536;  // entries one accumulate workgroup takes
+constexpr uint32_t kAccThreads = 512;
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -36,6 +41,30 @@ __device__ __forceinline__ uint32_t offset_of(uint32_t e) {
 }
 __device__ __forceinline__ void lds_inc(uint32_t *p) {
   __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
+}
+
+// Exclusive prefix of v over the workgroup's threads (in thread order) and the workgroup total.
+// wave_totals: LDS scratch of blockDim/64 words; the caller separates two calls by a barrier.
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *wave_totals,
+                                                         uint32_t *total) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += up;
+  }
+  if (lane == 63u) wave_totals[wid] = inc;
+  __syncthreads();
+  uint32_t before = 0, all = 0;
+  const uint32_t n_waves = blockDim.x >> 6;
+  for (uint32_t k = 0; k < n_waves; ++k) {
+    const uint32_t wt = wave_totals[k];
+    if (k < wid) before += wt;
+    all += wt;
+  }
+  *total = all;
+  return before + inc - v;
 }
 
 __global__ void __launch_bounds__(256) bin_count_kernel(BinLayout b) {
@@ -58,70 +87,93 @@ __global__ void __launch_bounds__(256) bin_count_kernel(BinLayout b) {
     lds_inc(&lds[tile_of(src[i], b.tiles_x)]);
   }
   __syncthreads();
-  uint32_t *dst = b.count + (size_t) wv * b.n_tiles;
-  for (uint32_t t = threadIdx.x; t < b.n_tiles; t += blockDim.x) dst[t] = lds[t];
-}
-
-// count[w][t] <- sum of count[w'][t] for w' < w; tile_base[t] <- total of tile t (scanned next).
-__global__ void __launch_bounds__(256) bin_scan_waves_kernel(BinLayout b) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= b.n_tiles) return;
-  unsigned long long run = 0;
-  for (uint32_t w = 0; w < b.n_waves; ++w) {
-    uint32_t *p = b.count + (size_t) w * b.n_tiles + t;
-    const uint32_t c = *p;
-    *p = (uint32_t) run;
-    run += c;
+  // tile-major: the scan over waves reads each tile's row contiguously
+  for (uint32_t t = threadIdx.x; t < b.n_tiles; t += blockDim.x) {
+    b.count[(size_t) t * b.n_waves + wv] = lds[t];
   }
-  b.tile_base[t] = run;
 }
 
-// tile_base[t] <- sum of totals of tiles < t; tile_base[n_tiles] <- grand total.  One workgroup.
+// count[t][w] <- sum of count[t][w'] for w' < w; tile_base[t] <- total of tile t (scanned next).
+__global__ void __launch_bounds__(256) bin_scan_waves_kernel(BinLayout b) {
+  __shared__ uint32_t wave_totals[4];
+  uint32_t *row = b.count + (size_t) blockIdx.x * b.n_waves;
+  const uint32_t per = (b.n_waves + blockDim.x - 1u) / blockDim.x;
+  const uint32_t w0 = threadIdx.x * per;
+  uint32_t sum = 0;
+  for (uint32_t k = 0; k < per; ++k) {
+    if (w0 + k < b.n_waves) sum += row[w0 + k];
+  }
+  uint32_t total = 0;
+  uint32_t run = block_exclusive_scan(sum, wave_totals, &total);
+  for (uint32_t k = 0; k < per; ++k) {
+    if (w0 + k < b.n_waves) {
+      const uint32_t c = row[w0 + k];
+      row[w0 + k] = run;
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) b.tile_base[blockIdx.x] = total;
+}
+
+// tile_base[t] <- sum of totals of tiles < t (tile_base[n_tiles] <- grand total), and
+// slice_base[t] <- number of accumulate slices of tiles < t.  One workgroup.
 __global__ void __launch_bounds__(1024) bin_scan_tiles_kernel(BinLayout b) {
   __shared__ unsigned long long part[1024];
+  __shared__ uint32_t wave_totals[16];
   constexpr uint32_t kPer = kMaxTiles / 1024;  // 4 tiles per thread
   unsigned long long v[kPer];
   unsigned long long sum = 0;
+  uint32_t slices = 0;
   for (uint32_t k = 0; k < kPer; ++k) {
     const uint32_t t = threadIdx.x * kPer + k;
     v[k] = t < b.n_tiles ? b.tile_base[t] : 0ull;
     sum += v[k];
+    slices += (uint32_t) ((v[k] + kSliceEntries - 1u) / kSliceEntries);
   }
   part[threadIdx.x] = sum;
   __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan (64-bit)
     const unsigned long long add = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
     __syncthreads();
     part[threadIdx.x] += add;
     __syncthreads();
   }
+  uint32_t slice_total = 0;
+  uint32_t srun = block_exclusive_scan(slices, wave_totals, &slice_total);
   unsigned long long run = part[threadIdx.x] - sum;
   for (uint32_t k = 0; k < kPer; ++k) {
     const uint32_t t = threadIdx.x * kPer + k;
-    if (t < b.n_tiles) b.tile_base[t] = run;
+    if (t < b.n_tiles) {
+      b.tile_base[t] = run;
+      b.slice_base[t] = srun;
+    }
     run += v[k];
+    srun += (uint32_t) ((v[k] + kSliceEntries - 1u) / kSliceEntries);
   }
-  if (threadIdx.x == 1023) b.tile_base[b.n_tiles] = part[1023];
+  if (threadIdx.x == 1023) {
+    b.tile_base[b.n_tiles] = part[1023];
+    b.slice_base[b.n_tiles] = slice_total;
+  }
 }
 
 __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout b) {
   extern __shared__ uint32_t lds[];
-  // dynamic LDS: cursor[n_tiles] | cnt[n_tiles] | lstart[n_tiles] | part[512] | pos[chunk] | off[chunk]
+  // dynamic LDS: cursor[n_tiles] | cnt[n_tiles] | lstart[n_tiles] | wave_totals[8] | pos[chunk] | off[chunk]
   uint32_t *cursor = lds;
   uint32_t *cnt = cursor + b.n_tiles;
   uint32_t *lstart = cnt + b.n_tiles;
-  uint32_t *part = lstart + b.n_tiles;
-  uint32_t *pos = part + kScatterThreads;
+  uint32_t *wave_totals = lstart + b.n_tiles;
+  uint32_t *pos = wave_totals + 8;
   uint16_t *off = reinterpret_cast<uint16_t *>(pos + kChunkEntries);
 
   const uint32_t wv = blockIdx.x;
   const uint32_t n = b.wave_count[wv];
+  if (n == 0) return;
   const uint32_t *src = b.stream + (size_t) wv * b.cap;
-  const uint32_t *prefix = b.count + (size_t) wv * b.n_tiles;
   for (uint32_t t = threadIdx.x; t < b.n_tiles; t += kScatterThreads) {
-    cursor[t] = (uint32_t) b.tile_base[t] + prefix[t];  // all entries together are < 2^32
+    // all entries together are < 2^32, so 32-bit places suffice
+    cursor[t] = (uint32_t) b.tile_base[t] + b.count[(size_t) t * b.n_waves + wv];
   }
-  // bins per thread for the in-chunk scan
   const uint32_t bins_per_thread = (b.n_tiles + kScatterThreads - 1u) / kScatterThreads;
 
   for (uint32_t base = 0; base < n; base += kChunkEntries) {
@@ -133,10 +185,13 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
-      e[k] = 0u;
+      e[k] = (i < m) ? src[base + i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+      const uint32_t i = k * kScatterThreads + threadIdx.x;
       r[k] = 0u;
       if (i < m) {
-        e[k] = src[base + i];
         r[k] = __hip_atomic_fetch_add(&cnt[tile_of(e[k], b.tiles_x)], 1u, __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
       }
@@ -147,28 +202,19 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
       const uint32_t t0 = threadIdx.x * bins_per_thread;
       uint32_t sum = 0;
       for (uint32_t k = 0; k < bins_per_thread; ++k) {
-        const uint32_t t = t0 + k;
-        if (t < b.n_tiles) sum += cnt[t];
+        if (t0 + k < b.n_tiles) sum += cnt[t0 + k];
       }
-      part[threadIdx.x] = sum;
-      __syncthreads();
-      for (uint32_t d = 1; d < kScatterThreads; d <<= 1) {
-        const uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-      }
-      uint32_t run = part[threadIdx.x] - sum;
+      uint32_t total = 0;
+      uint32_t run = block_exclusive_scan(sum, wave_totals, &total);
       for (uint32_t k = 0; k < bins_per_thread; ++k) {
-        const uint32_t t = t0 + k;
-        if (t < b.n_tiles) {
-          lstart[t] = run;
-          run += cnt[t];
+        if (t0 + k < b.n_tiles) {
+          lstart[t0 + k] = run;
+          run += cnt[t0 + k];
         }
       }
     }
     __syncthreads();
-    // 3. sort the chunk in LDS: destination index in `sorted` and in-tile offset, tile by tile
+    // 3. sort the chunk in LDS: destination place in `sorted` and in-tile offset, tile by tile
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
@@ -187,22 +233,54 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
   }
 }
 
-__global__ void __launch_bounds__(512) bin_accumulate_kernel(BinLayout b, unsigned long long *hist,
-                                                             int w, int h) {
+__global__ void __launch_bounds__(kAccThreads) bin_accumulate_kernel(BinLayout b,
+                                                                     unsigned long long *hist,
+                                                                     int w, int h) {
   __shared__ uint32_t tile[kTilePixels];  // 64 KiB
-  const uint32_t t = blockIdx.x;
-  const unsigned long long begin = b.tile_base[t];
-  const unsigned long long end = b.tile_base[t + 1];
-  if (begin == end) return;  // wave-uniform: nothing landed on this tile
-  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += blockDim.x) tile[p] = 0u;
+  // which (tile, slice) is this workgroup?  slice_base is an exclusive prefix: binary search
+  const uint32_t s = blockIdx.x;
+  if (s >= b.slice_base[b.n_tiles]) return;  // the grid is an upper bound
+  uint32_t lo = 0, hi = b.n_tiles;  // invariant: slice_base[lo] <= s < slice_base[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (b.slice_base[mid] <= s) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const uint32_t t = lo;
+  const unsigned long long tile_begin = b.tile_base[t], tile_end = b.tile_base[t + 1];
+  const unsigned long long begin = tile_begin + (unsigned long long) (s - b.slice_base[t]) * kSliceEntries;
+  const unsigned long long end = (begin + kSliceEntries < tile_end) ? begin + kSliceEntries : tile_end;
+
+  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) tile[p] = 0u;
   __syncthreads();
-  for (unsigned long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
-    lds_inc(&tile[b.sorted[i]]);
+  // head up to a 16-byte boundary, then 8 entries per load, then the tail
+  const uint16_t *src = b.sorted;
+  unsigned long long body = (begin + 7ull) & ~7ull;
+  if (body > end) body = end;
+  for (unsigned long long i = begin + threadIdx.x; i < body; i += kAccThreads) lds_inc(&tile[src[i]]);
+  const unsigned long long n8 = (end - body) >> 3;
+  const uint4 *src8 = reinterpret_cast<const uint4 *>(src + body);
+  for (unsigned long long i = threadIdx.x; i < n8; i += kAccThreads) {
+    const uint4 v = src8[i];
+    lds_inc(&tile[v.x & 0xffffu]);
+    lds_inc(&tile[v.x >> 16]);
+    lds_inc(&tile[v.y & 0xffffu]);
+    lds_inc(&tile[v.y >> 16]);
+    lds_inc(&tile[v.z & 0xffffu]);
+    lds_inc(&tile[v.z >> 16]);
+    lds_inc(&tile[v.w & 0xffffu]);
+    lds_inc(&tile[v.w >> 16]);
+  }
+  for (unsigned long long i = body + (n8 << 3) + threadIdx.x; i < end; i += kAccThreads) {
+    lds_inc(&tile[src[i]]);
   }
   __syncthreads();
   const uint32_t row0 = (t / b.tiles_x) << kTileShift;
   const uint32_t col0 = (t % b.tiles_x) << kTileShift;
-  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += blockDim.x) {
+  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) {
     const uint32_t v = tile[p];
     if (v != 0u) {
       const uint32_t row = row0 + (p >> kTileShift);
@@ -218,9 +296,10 @@ __global__ void __launch_bounds__(512) bin_accumulate_kernel(BinLayout b, unsign
 }  // namespace
 
 size_t bin_fixed_bytes(uint32_t n_waves, uint32_t n_tiles) {
-  return round_up((size_t) n_waves * sizeof(uint32_t), 256) +
-         round_up((size_t) n_waves * n_tiles * sizeof(uint32_t), 256) +
-         round_up(((size_t) n_tiles + 1) * sizeof(unsigned long long), 256) + 512;
+  return round_up((size_t) n_waves * sizeof(uint32_t), 256) +                   // wave_count
+         round_up((size_t) n_waves * n_tiles * sizeof(uint32_t), 256) +         // count
+         round_up(((size_t) n_tiles + 1) * sizeof(unsigned long long), 256) +   // tile_base
+         round_up(((size_t) n_tiles + 1) * sizeof(uint32_t), 256) + 1024;       // slice_base + slack
 }
 
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves) {
@@ -234,6 +313,7 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   b.stream = nullptr;
   b.count = nullptr;
   b.tile_base = nullptr;
+  b.slice_base = nullptr;
   b.sorted = nullptr;
   if (!workspace || n_waves == 0 || w <= 0 || h <= 0 || w > 65536 || h > 65536) return b;
   const uint32_t tiles_x = ((uint32_t) w + kTileSize - 1u) >> kTileShift;
@@ -259,6 +339,8 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   p += round_up((size_t) n_waves * b.n_tiles * sizeof(uint32_t), 256);
   b.tile_base = reinterpret_cast<unsigned long long *>(p);
   p += round_up(((size_t) b.n_tiles + 1) * sizeof(unsigned long long), 256);
+  b.slice_base = reinterpret_cast<uint32_t *>(p);
+  p += round_up(((size_t) b.n_tiles + 1) * sizeof(uint32_t), 256);
   b.stream = reinterpret_cast<uint32_t *>(p);
   p += (size_t) n_waves * b.cap * sizeof(uint32_t);
   p = (p + 255) & ~(uintptr_t) 255;
@@ -272,17 +354,20 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   if (!b.enabled) return hipSuccess;
   const size_t count_lds = (size_t) b.n_tiles * sizeof(uint32_t);
   hipLaunchKernelGGL(bin_count_kernel, dim3(b.n_waves), dim3(256), count_lds, stream, b);
-  hipLaunchKernelGGL(bin_scan_waves_kernel, dim3((b.n_tiles + 255u) / 256u), dim3(256), 0, stream, b);
+  hipLaunchKernelGGL(bin_scan_waves_kernel, dim3(b.n_tiles), dim3(256), 0, stream, b);
   hipLaunchKernelGGL(bin_scan_tiles_kernel, dim3(1), dim3(1024), 0, stream, b);
-  const size_t scatter_lds = ((size_t) 3 * b.n_tiles + kScatterThreads + kChunkEntries) * sizeof(uint32_t) +
+  const size_t scatter_lds = ((size_t) 3 * b.n_tiles + 8 + kChunkEntries) * sizeof(uint32_t) +
                              (size_t) kChunkEntries * sizeof(uint16_t);
-  if (scatter_lds > 64 * 1024) {  // up to 98 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
+  if (scatter_lds > 64 * 1024) {  // up to 96 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_scatter_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) scatter_lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(b.n_waves), dim3(kScatterThreads), scatter_lds, stream, b);
-  hipLaunchKernelGGL(bin_accumulate_kernel, dim3(b.n_tiles), dim3(512), 0, stream, b, hist, w, h);
+  // upper bound on the number of slices: one partial slice per tile + the full ones
+  const unsigned long long max_entries = (unsigned long long) b.n_waves * b.cap;
+  const uint32_t slices = b.n_tiles + (uint32_t) (max_entries / kSliceEntries) + 1u;
+  hipLaunchKernelGGL(bin_accumulate_kernel, dim3(slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
   return hipGetLastError();
 }
 

@@ -61,13 +61,18 @@ typedef struct {
   uint64_t never_escaped;  /* IterateMandelbrot returned max (cudabrot.cu:407)           */
   uint64_t too_fast;       /* escaped before min_escape_iterations (cudabrot.cu:408)     */
   uint64_t recorded;       /* orbits replayed (cudabrot.cu:412)                          */
-  uint64_t iterate_steps;  /* z<-z^2+c iterations of IterateMandelbrot (cudabrot.cu:326) */
+  uint64_t iterate_steps;  /* z<-z^2+c iterations of IterateMandelbrot (cudabrot.cu:326),
+                              as the reference would execute them                        */
   uint64_t replay_steps;   /* iterations of IterateAndRecord (cudabrot.cu:352)           */
   uint64_t increments;     /* histogram increments (cudabrot.cu:312)                     */
-  uint64_t reserved;       /* always 0                                                   */
+  uint64_t skipped_steps;  /* part of iterate_steps NOT executed: the orbit was found to be
+                              exactly periodic, so it can never escape                   */
   uint64_t status;         /* 0 = ok; nonzero = internal invariant violated (CB_STATUS_*) */
   /* CB_KERNEL_TIMED only (else 0): shader-clock cycles summed over waves, per stage and in total */
   uint64_t cycles_head, cycles_long, cycles_replay, cycles_total;
+  /* CB_KERNEL_TIMED only, 100 MHz constant clock, LAST launch only meaningful if counters were zeroed
+   * before it: ~(earliest wave start), latest wave end, sum of wave lifetimes */
+  uint64_t rt_not_first_start, rt_last_end, rt_wave_life_sum;
 } cb_counters;
 
 #define CB_STATUS_QUEUE_OVERFLOW 1u

@@ -28,7 +28,7 @@ def test_struct_layouts_match_the_reference_kernel_arguments(cb):
     # FractalDimensions is 56 bytes, IterationControl 8 (cudabrot.cu:46-67)
     assert C.sizeof(cb.FractalDimensions) == 56
     assert C.sizeof(cb.IterationControl) == 8
-    assert C.sizeof(cb.Counters) == 112
+    assert C.sizeof(cb.Counters) == 136
     assert cb.FractalDimensions.delta_real.offset == 40
 
 

@@ -181,7 +181,7 @@ def _torch_render(cb, w, h, max_iter, min_iter, t, passes, workspace_bytes, box=
     it = cb.IterationControl(max_iter, min_iter)
     states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
     hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
-    counters = torch.zeros(14, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
     ws = torch.empty(max(workspace_bytes, 1), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
@@ -229,7 +229,7 @@ def test_low_level_entry_points_on_torch_memory(cb, oracle):
     it = cb.IterationControl(300, 20)
     states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
     hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
-    counters = torch.zeros(14, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
     for _ in range(3):

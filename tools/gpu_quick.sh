@@ -17,6 +17,12 @@ if ! grep -q " passed" gpurun_out/pytest_gpu.log || grep -q "failed" gpurun_out/
   grep -E "^E |Error|FAILED" gpurun_out/pytest_gpu.log | head -30
   if [ "${FORCE:-0}" != "1" ]; then echo "PARITY NOT GREEN: stopping"; exit 1; fi
 fi
+export TMPDIR=/tmp
+rm -rf gpurun_out/prof_cli
+TAILN=2 run 200 gpurun_out/prof_cli.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cli -- ./cudabrot --passes 128 -w 4096 -h 4096 -m 20000 -o /dev/null
+cut -d, -f1-4 gpurun_out/prof_cli/*/*_kernel_stats.csv | cut -c1-150
+TAILN=2 run 200 gpurun_out/prof_cli_def.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_cli_def -- ./cudabrot --passes 256 -o /dev/null
+cut -d, -f1-4 gpurun_out/prof_cli_def/*/*_kernel_stats.csv | cut -c1-150
 run 100 gpurun_out/mine_c3.log ./cudabrot -t 10 -w 4096 -h 4096 -m 20000 --stats -o /dev/null
 run 100 gpurun_out/mine_c3_timed.log ./cudabrot -t 5 -w 4096 -h 4096 -m 20000 --stats --kernel timed -o /dev/null
 run 100 gpurun_out/mine_c2.log ./cudabrot -t 5 -w 4096 -h 4096 -m 2000 --stats -o /dev/null
