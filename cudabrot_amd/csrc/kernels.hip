@@ -387,6 +387,144 @@ __device__ __forceinline__ unsigned long long iterate_steps(unsigned long long m
   return escaped;
 }
 
+// ---- REPLAY burst: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream ------------------
+//
+// One step for the lanes of `act` (EXEC), in the order of the reference's loop body:
+//   z <- z^2 + c            (CB_STEP's seven fp64 instructions, same order)
+//   IncrementPixelCounter   if (re >= min_re && im >= min_im) { col = (int)((re-min_re)/d_re); row
+//                           likewise; if (col <u w && row <u h) append row<<16|col to the stream }
+//                           (cudabrot.cu:308-312; the unsigned compares also reject the saturated
+//                           conversions, and col, row cannot be negative past the first test)
+//   if (|z|^2 > 4) leave    (cudabrot.cu:363) -- after recording the escaped point, like the reference
+// The hits of a step are compacted with v_mbcnt and stored side by side (one coalesced store).
+// x / delta: an exact multiply when both deltas are powers of two (CB_REPLAY_BIN_POW2), else the
+// correctly rounded IEEE quotient by the same instruction sequence hipcc emits for a double
+// division (CB_REPLAY_BIN_DIV: v_div_scale / v_rcp / Newton steps / v_div_fmas / v_div_fixup).
+#define CB_REPLAY_BIN_POW2                                \
+  "v_mul_f64 %[fx], %[fx], %[sx]\n\t"                     \
+  "v_mul_f64 %[fy], %[fy], %[sy]\n\t"
+#define CB_DIV(q, num, den)                                         \
+  "v_div_scale_f64 %[d0], %[scp], " den ", " den ", " num "\n\t"    \
+  "v_rcp_f64 %[d2], %[d0]\n\t"                                      \
+  "v_div_scale_f64 %[d1], vcc, " num ", " den ", " num "\n\t"       \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_mul_f64 %[d3], %[d1], %[d2]\n\t"                               \
+  "v_fma_f64 %[d0], -%[d0], %[d3], %[d1]\n\t"                       \
+  "v_div_fmas_f64 %[d0], %[d0], %[d2], %[d3]\n\t"                   \
+  "v_div_fixup_f64 " q ", %[d0], " den ", " num "\n\t"
+#define CB_REPLAY_BIN_DIV CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]")
+
+#define CB_REPLAY_HEAD                                    \
+  "s_mov_b64 %[save], exec\n\t"                           \
+  "s_mov_b32 %[cs], 0\n\t"                                \
+  "s_mov_b32 %[ch], 0\n\t"                                \
+  "s_mov_b32 %[ctr], %[n]\n\t"                            \
+  "1:\n\t"                                                \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
+  "v_add_f64 %[b], %[r], %[r]\n\t"                        \
+  "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
+  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"                 \
+  "v_add_f64 %[r], %[cr], %[a]\n\t"                       \
+  "v_add_u32 %[ps], 1, %[ps]\n\t"                         \
+  "v_add_f64 %[fy], %[i], -%[miny]\n\t"                   \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_add_f64 %[fx], %[r], -%[minx]\n\t"                   \
+  "v_cmp_le_f64_e64 %[hy], %[miny], %[i]\n\t"             \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "v_cmp_le_f64_e64 %[hx], %[minx], %[r]\n\t"
+#define CB_REPLAY_TAIL                                    \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_cmp_nlt_f64_e64 %[alive], 4.0, %[a]\n\t"             \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
+  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
+  "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"         \
+  "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_cmp_eq_u64 %[act], 0\n\t"                            \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
+  "s_cbranch_scc1 1b\n\t"                                 \
+  "2:\n\t"                                                \
+  "s_mov_b64 exec, %[save]\n\t"                           \
+  "s_nop 4\n\t"
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+  return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __longlong_as_double((long long) uniform_u64((unsigned long long) __double_as_longlong(v)));
+}
+
+// Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for
+// 64 * n_steps more entries.  On return `act` holds the lanes still replaying, `fill` the new fill,
+// lane_steps / hits the executed lane-steps and the entries appended.
+template <bool kPow2>
+__device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
+                                             int &p_steps, const Canvas &cv, uint32_t *region,
+                                             uint32_t &fill, uint32_t &lane_steps, uint32_t &hits) {
+  unsigned long long save, alive, hx, hy, scp;
+  uint32_t cs, ch, ctr, t;
+  double a, b, fx, fy, d0, d1, d2, d3;
+  uint32_t col, row, pidx, e;
+  // x / delta as an exact multiply (kPow2) or a true division: the scale operands.  All "s"
+  // operands are wave-uniform by construction; uniform64/readfirstlane make that provable.
+  const double sx = uniform_f64(kPow2 ? cv.inv_delta_real : cv.delta_real);
+  const double sy = uniform_f64(kPow2 ? cv.inv_delta_imag : cv.delta_imag);
+  const double minx = uniform_f64(cv.min_real), miny = uniform_f64(cv.min_imag);
+  const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t) cv.w);
+  const uint32_t h = __builtin_amdgcn_readfirstlane((uint32_t) cv.h);
+  region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
+  act = uniform_u64(act);
+  fill = __builtin_amdgcn_readfirstlane(fill);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  if (kPow2) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
+                   [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
+                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
+                   [base] "s"(region)
+                 : "vcc", "scc", "memory");
+  } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
+                   [a] "=&v"(a), [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
+                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
+                   [base] "s"(region)
+                 : "vcc", "scc", "memory");
+  }
+  lane_steps = cs;
+  hits = ch;
+}
+
 __device__ __forceinline__ bool lane_in(unsigned long long mask) {
   return (mask >> lane_id()) & 1ull;
 }
@@ -439,7 +577,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
   unsigned long long skipped_steps = 0;  // per lane: iterations the periodicity check made unnecessary
   int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
   // REPLAY lane state
-  double p_cr = 0, p_ci = 0, p_r = 0, p_i = 0;
+  Orbit po = {0, 0, 0, 0};
   bool p_act = false;
   int p_steps = 0;
 
@@ -462,10 +600,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
             const int rank = mask_prefix(idle_mask);
             if (!p_act && rank < n) {
               const int slot = (q2_head + rank) & (kQ2Cap - 1);
-              p_cr = q.q2_cr[slot];
-              p_ci = q.q2_ci[slot];
-              p_r = p_cr;
-              p_i = p_ci;
+              po.cr = q.q2_cr[slot];
+              po.ci = q.q2_ci[slot];
+              po.r = po.cr;
+              po.i = po.ci;
               p_steps = 0;
               p_act = true;
             }
@@ -478,19 +616,37 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
         if (n_act == 0) break;
         if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
 
+        // kBinned: the visited pixels go to this wave's stream region (compacted, coalesced stores)
+        // in a hand-written burst; a full region falls back to the direct-atomics loop below, so
+        // the result never depends on the workspace size.
+        if (kBinned && region_fill + 64u * kReplayBurst <= region_cap) {
+          unsigned long long act_mask = __ballot(p_act);
+          uint32_t steps = 0, hits = 0;
+          if (cv.pow2_real && cv.pow2_imag) {
+            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+          } else {
+            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+          }
+          n_replay += steps;
+          n_incr += hits;
+          p_act = lane_in(act_mask);
+          if (__ballot(p_act && p_steps > max_iter) != 0ull) {
+            // cannot happen: the orbit escaped within max_iter steps in the HEAD/LONG stage
+            status |= CB_STATUS_REPLAY_RUNAWAY;
+            if (p_steps > max_iter) p_act = false;
+          }
+          continue;
+        }
         for (int b = 0; b < kReplayBurst; ++b) {
           const unsigned long long act_mask = __ballot(p_act);
           if (act_mask == 0ull) break;
           n_replay += (unsigned long long) __popcll(act_mask);
           bool done = false, hit = false;
-          // kBinned: the visited pixels go to this wave's stream region (compacted, coalesced
-          // stores); a full region falls back to direct atomics, so results never depend on it.
-          const bool to_stream = kBinned && (region_fill + 64u <= region_cap);
           int row = 0, col = 0;
           if (p_act) {
-            const double m = mandel_step(p_cr, p_ci, p_r, p_i);       // cudabrot.cu:357-359
-            hit = pixel_of(p_r, p_i, cv, row, col);                   // cudabrot.cu:308-311
-            if (hit && !to_stream) add_to_pixel(a.hist, cv, row, col, 1ull);  // cudabrot.cu:312
+            const double m = mandel_step(po.cr, po.ci, po.r, po.i);   // cudabrot.cu:357-359
+            hit = pixel_of(po.r, po.i, cv, row, col);                 // cudabrot.cu:308-311
+            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);        // cudabrot.cu:312
             p_steps++;
             done = m > 4.0;                                           // cudabrot.cu:363
             if (!done && p_steps > max_iter) {
@@ -500,15 +656,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
             }
             if (done) p_act = false;
           }
-          const unsigned long long hit_mask = __ballot(hit);
-          n_incr += (unsigned long long) __popcll(hit_mask);
-          if (kBinned && to_stream && hit_mask != 0ull) {
-            if (hit) {
-              region[region_fill + (uint32_t) mask_prefix(hit_mask)] =
-                  ((uint32_t) row << 16) | (uint32_t) col;
-            }
-            region_fill += (uint32_t) __popcll(hit_mask);
-          }
+          n_incr += (unsigned long long) __popcll(__ballot(hit));
           if (__ballot(done) != 0ull && q2_count > 0) break;
         }
       }
