@@ -77,7 +77,10 @@ def recorded_traffic(samples_per_step):
         try:
             s = json.load(open(f))
             if s["bench_line"]["config"]["samples_per_step_per_gpu"] == samples_per_step:
-                best = (s["traffic_bytes_per_dispatch"]["total"], os.path.relpath(f, ROOT))
+                t = s["traffic_bytes_per_launch"]
+                best = {"draw": t["draw_wave_kernel"]["total"], "scatter": t["scatter_kernels"]["total"],
+                        "source": os.path.relpath(f, ROOT),
+                        "scatter_mode": s["bench_line"]["config"].get("scatter", "")[:8]}
         except (KeyError, TypeError, ValueError):
             continue
     return best
@@ -116,6 +119,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
+    ap.add_argument("--no-full-iterate", action="store_true",
+                    help="skip the extra two launches that measure the iterate loop with the early-out off")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
     args = ap.parse_args()
@@ -213,7 +218,8 @@ def main():
         assert total_incr >= cnt["increments"] and (warm > 0 or total_incr == cnt["increments"])
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         avg_flush_ms = sum(flush_ms) / len(flush_ms)
-        iters_per_launch = (loc["iterate_steps"] + loc["replay_steps"]) / args.steps
+        # EXECUTED iterations: the reference's count minus what the exact-periodicity check retired early
+        iters_per_launch = (loc["iterate_steps"] - loc["skipped_steps"] + loc["replay_steps"]) / args.steps
         incr_per_launch = loc["increments"] / args.steps
         traffic = recorded_traffic(threads * samples_per_thread)
         tflops = iters_per_launch * FLOPS_PER_ITERATION / (avg_ms * 1e-3) / 1e12
@@ -246,6 +252,10 @@ def main():
             "escaping_points_per_sec": round(cnt["recorded"] / elapsed, 1),
             "increments_per_sec": round(cnt["increments"] / elapsed, 1),
             "iterations_per_sample": round((cnt["iterate_steps"] + cnt["replay_steps"]) / cnt["samples"], 3),
+            "executed_iterations_per_sample": round(
+                (cnt["iterate_steps"] - cnt["skipped_steps"] + cnt["replay_steps"]) / cnt["samples"], 3),
+            "reference_equivalent_tflops": round(
+                (cnt["iterate_steps"] + cnt["replay_steps"]) * FLOPS_PER_ITERATION / elapsed / 1e12, 2),
             "roofline": {
                 "bound": "valu_fp64",
                 "kernel": "draw_wave_kernel",
@@ -256,10 +266,14 @@ def main():
                 "issue_frac": round(tflops / FLOPS_PER_ITERATION * 8 / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_flops_per_launch": iters_per_launch * FLOPS_PER_ITERATION,
-                "traffic": None,
-                "note": "no MFMA: the path has no contraction; 10 flops per z<-z^2+c iteration over the executed "
-                        "iterations counted in-kernel; ceiling of `frac` for the 7-op+compare sequence is 0.625; "
-                        "issue_frac = fp64 issue-slot utilisation (8 per iteration)",
+                "traffic": traffic["draw"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "note": "no MFMA: the path has no contraction; 10 flops per z<-z^2+c iteration over the iterations "
+                        "the kernel EXECUTED (counted in-kernel; orbits found exactly periodic are retired early "
+                        "with the identical outcome, so at max_iter=20000 only ~14 % of the reference's iterations "
+                        "are executed); the kernel also draws, tests and replays, so this is a lower bound on its "
+                        "fp64 use; ceiling of `frac` for the 7-op+compare sequence is 0.625; issue_frac = fp64 "
+                        "issue-slot utilisation (8 per iteration)",
             },
             "roofline_scatter": {
                 "bound": "hbm",
@@ -270,12 +284,42 @@ def main():
                 "unit": "GB/s",
                 "frac": round(scatter_gbps / PEAK_HBM_GBPS, 5),
                 "algorithmic_bytes_per_launch": incr_per_launch * BYTES_PER_INCREMENT,
-                "traffic": traffic[0] if traffic else None,
-                "traffic_source": traffic[1] if traffic else None,
+                "traffic": traffic["scatter"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
                 "note": "16 B per histogram increment (u64 read+write), increments counted in-kernel, over the time "
                         "of the scatter kernels; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale)",
             },
         }
+        if world == 1 and not args.no_full_iterate:
+            # the iterate loop against its roofline: the same launch with the periodicity early-out off,
+            # i.e. every sample iterated to max_iter as the reference does (same histogram)
+            counters.zero_()
+            torch.cuda.synchronize()
+            fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(2)]
+            for a, b in fev:
+                a.record()
+                cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
+                                   counters.data_ptr(), cb.CB_KERNEL_FULL_ITERATE, stream,
+                                   workspace.data_ptr() if ws_bytes else 0, ws_bytes)
+                b.record()
+                flush()
+            torch.cuda.synchronize()
+            fms = sum(a.elapsed_time(b) for a, b in fev) / len(fev)
+            fc = dict(zip(cnt.keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
+            fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / len(fev)
+            ftf = fiters * FLOPS_PER_ITERATION / (fms * 1e-3) / 1e12
+            line["roofline_full_iterate"] = {
+                "bound": "valu_fp64",
+                "kernel": "draw_wave_kernel (CB_KERNEL_FULL_ITERATE: early-out off, %.1f iterations/sample executed)"
+                          % (fiters / (threads * samples_per_thread)),
+                "achieved": round(ftf, 3),
+                "peak": PEAK_FP64_VECTOR_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
+                "issue_frac": round(ftf / FLOPS_PER_ITERATION * 8 / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+                "avg_launch_ms": round(fms, 4),
+                "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
+            }
         if world == 1 and not args.no_reference:
             ref = reference_gpu()
             if ref:

@@ -20,6 +20,7 @@ CB_DEFAULT_RNG_SEED = 1337  # cudabrot.cu:37
 CB_KERNEL_DEFAULT = 0
 CB_KERNEL_SIMPLE = 1
 CB_KERNEL_TIMED = 2
+CB_KERNEL_FULL_ITERATE = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -88,6 +88,7 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.bin = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
                               cb::draw_wave_count(n_threads));
   a.wave_dump = g_wave_dump;
+  a.check_periodic = 1;
   return a;
 }
 
@@ -106,10 +107,16 @@ struct cb_renderer {
   cb_pixel *d_hist;
   uint32_t *d_states;
   cb_counters *d_counters;
-  void *d_workspace;       // scatter workspace, allocated on first use
+  // Scatter workspaces, allocated on first use.  Two of them, so that the flush of launch n (on
+  // flush_stream) overlaps the draw kernel of launch n+1 (on stream): the flush is HBM/LDS work, the
+  // draw kernel is fp64 work.
+  void *d_workspace[2];
   size_t workspace_bytes;
   int workspace_tried;
-  hipStream_t stream;
+  int next_workspace;
+  bool flush_pending[2];
+  hipEvent_t draw_done[2], flush_done[2];
+  hipStream_t stream, flush_stream;
 };
 
 extern "C" {
@@ -183,6 +190,11 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   switch (kernel_variant) {
     case CB_KERNEL_DEFAULT:
       return (int) cb::launch_draw_wave(a, false, s);
+    case CB_KERNEL_FULL_ITERATE: {
+      cb::DrawArgs full = a;
+      full.check_periodic = 0;
+      return (int) cb::launch_draw_wave(full, false, s);
+    }
     case CB_KERNEL_TIMED:
       return (int) cb::launch_draw_wave(a, true, s);
     case CB_KERNEL_SIMPLE:
@@ -219,6 +231,11 @@ int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimension
   r->n_threads = n_threads;
   const size_t hist_bytes = (size_t) dims->w * (size_t) dims->h * sizeof(cb_pixel);
   hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->flush_stream, hipStreamNonBlocking);
+  for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    e = hipEventCreateWithFlags(&r->draw_done[k], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->flush_done[k], hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMalloc(&r->d_hist, hist_bytes);                  // cudabrot.cu:168
   if (e == hipSuccess) e = hipMemsetAsync(r->d_hist, 0, hist_bytes, r->stream);  // cudabrot.cu:169
   if (e == hipSuccess) e = hipMalloc(&r->d_states, cb_rng_state_bytes(n_threads));  // :177
@@ -254,28 +271,45 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
                                              max_passes_per_launch * CB_SAMPLES_PER_THREAD);
     size_t free_b = 0, total_b = 0;
     if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-      if (want > free_b / 2) want = free_b / 2;
-      if (hipMalloc(&r->d_workspace, want) == hipSuccess) {
+      if (want > free_b / 4) want = free_b / 4;
+      if (hipMalloc(&r->d_workspace[0], want) == hipSuccess &&
+          hipMalloc(&r->d_workspace[1], want) == hipSuccess) {
         r->workspace_bytes = want;
       } else {
         (void) hipGetLastError();
-        r->d_workspace = nullptr;
+        (void) hipFree(r->d_workspace[0]);
+        (void) hipFree(r->d_workspace[1]);
+        r->d_workspace[0] = r->d_workspace[1] = nullptr;
       }
     }
   }
+  const bool deferred = r->d_workspace[0] && kernel_variant != CB_KERNEL_SIMPLE;
   while (passes > 0) {
     const uint32_t now = passes < max_passes_per_launch ? passes : max_passes_per_launch;
+    const int k = r->next_workspace;
+    if (deferred && r->flush_pending[k]) {
+      // workspace k is free again once the flush that read it has finished
+      CB_TRY(hipStreamWaitEvent(r->stream, r->flush_done[k], 0));
+      r->flush_pending[k] = false;
+    }
     int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
                                 now * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
-                                r->d_workspace, r->workspace_bytes, r->stream);
+                                deferred ? r->d_workspace[k] : nullptr, r->workspace_bytes, r->stream);
     if (rc) return rc;
-    if (r->d_workspace && kernel_variant != CB_KERNEL_SIMPLE) {
-      rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace, r->workspace_bytes,
-                            r->stream);
+    if (deferred) {
+      CB_TRY(hipEventRecord(r->draw_done[k], r->stream));
+      CB_TRY(hipStreamWaitEvent(r->flush_stream, r->draw_done[k], 0));
+      rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace[k], r->workspace_bytes,
+                            r->flush_stream);
       if (rc) return rc;
+      CB_TRY(hipEventRecord(r->flush_done[k], r->flush_stream));
+      r->flush_pending[k] = true;
+      r->next_workspace = k ^ 1;
     }
     passes -= now;
   }
+  CB_TRY(hipStreamSynchronize(r->flush_stream));  // the histogram is complete when this call returns
+  r->flush_pending[0] = r->flush_pending[1] = false;
   if (g_wave_dump) {  // diagnostic: write the per-wave records of the last launch
     (void) hipStreamSynchronize(r->stream);
     const size_t n = (size_t) cb::draw_wave_count(r->n_threads) * 8;
@@ -322,11 +356,18 @@ void cb_renderer_destroy(cb_renderer *r) {
   if (!r) return;
   (void) hipSetDevice(r->device);
   if (r->stream) (void) hipStreamSynchronize(r->stream);
+  if (r->flush_stream) (void) hipStreamSynchronize(r->flush_stream);
   (void) hipFree(r->d_hist);
   (void) hipFree(r->d_states);
   (void) hipFree(r->d_counters);
-  (void) hipFree(r->d_workspace);
+  (void) hipFree(r->d_workspace[0]);
+  (void) hipFree(r->d_workspace[1]);
+  for (int k = 0; k < 2; ++k) {
+    if (r->draw_done[k]) (void) hipEventDestroy(r->draw_done[k]);
+    if (r->flush_done[k]) (void) hipEventDestroy(r->flush_done[k]);
+  }
   if (r->stream) (void) hipStreamDestroy(r->stream);
+  if (r->flush_stream) (void) hipStreamDestroy(r->flush_stream);
   delete r;
 }
 

@@ -146,6 +146,7 @@ const std::vector<Flag> &flag_table() {
        [](Settings &s, long, double, const char *t) {
          s.kernel_variant = (strcmp(t, "simple") == 0)  ? CB_KERNEL_SIMPLE
                             : (strcmp(t, "timed") == 0) ? CB_KERNEL_TIMED
+                            : (strcmp(t, "full") == 0)  ? CB_KERNEL_FULL_ITERATE
                                                         : CB_KERNEL_DEFAULT;
        }},
       {"--stats", Value::kNone, nullptr, false,

@@ -74,6 +74,9 @@ struct DrawArgs {
   // timed variant only, may be null: 8 words per wave {HW_ID, XCC_ID, start, end (100 MHz clock),
   // cycles in HEAD, LONG, REPLAY, total}
   unsigned long long *wave_dump;
+  // 1: retire orbits found exactly periodic (default); 0: iterate every sample to max_iter like the
+  // reference does (CB_KERNEL_FULL_ITERATE, for measuring the iterate loop against its roofline)
+  int check_periodic;
 };
 
 constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup

@@ -809,7 +809,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
           // outcome, without executing the remaining iterations.  Brent's scheme at chunk
           // granularity: compare with one saved point, re-save when the chunk count is a power
           // of two; a cycle of period p is found at most 16 p iterations after it has begun.
-          const bool periodic = (__double_as_longlong(lo[o].r) == __double_as_longlong(seen_r[o])) &&
+          const bool periodic = (a.check_periodic != 0) &&
+                                (__double_as_longlong(lo[o].r) == __double_as_longlong(seen_r[o])) &&
                                 (__double_as_longlong(lo[o].i) == __double_as_longlong(seen_i[o]));
           if (periodic && l_rem[o] > 0) {
             skipped_steps += (unsigned long long) l_rem[o];
@@ -888,12 +889,13 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
   const bool binned = a.bin.enabled != 0u;
   if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
-  // Unused dynamic LDS on top of the 32 KiB of queues: with 40 KiB per workgroup exactly four fit a
-  // CU (160 KiB), so the reference-sized grid (1024 workgroups) lands as 4 per CU = 4 waves per SIMD
-  // everywhere instead of 5 on some CUs and 3 on others.
+  // Experiment knob: unused dynamic LDS on top of the 32 KiB of queues (to cap workgroups per CU).
+  // The reference-sized grid (1024 workgroups) was measured to land as exactly 4 per CU = 4 waves per
+  // SIMD without any padding, so the default is none; free LDS lets scatter workgroups of the
+  // previous launch run beside this kernel.
   static const int lds_pad = [] {
     const char *e = getenv("CUDABROT_AMD_LDS_PAD");
-    return e ? atoi(e) : 8192;
+    return e ? atoi(e) : 0;
   }();
   if (timed && binned) {
     hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), lds_pad, stream, a);

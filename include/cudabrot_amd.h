@@ -82,6 +82,9 @@ typedef struct {
 #define CB_KERNEL_DEFAULT 0 /* wave-scheduled three-stage kernel (the product path)               */
 #define CB_KERNEL_SIMPLE 1  /* one lane = one reference thread, lock-step; a validation baseline  */
 #define CB_KERNEL_TIMED 2   /* the default kernel with per-stage s_memtime stamps (diagnostic build) */
+#define CB_KERNEL_FULL_ITERATE 3 /* the default kernel without the exact-periodicity early-out: every
+                                    sample is iterated to max_iter as the reference does (same result;
+                                    for measuring the iterate loop against the fp64 roofline)        */
 
 /* RecomputePixelDeltas (cudabrot.cu:505-527).  Returns 1 and fills delta_* if the canvas is valid,
  * else 0 and, if msg is not NULL, *msg points at the reference's message for the failed check. */

@@ -1,0 +1,137 @@
+"""The `cudabrot` binary end to end on a GPU: stdout sequence, PGM bytes, -s buffer semantics, SIGINT
+(cudabrot.cu:215-280, 471-501, 548-577, 756-791)."""
+
+import os
+import re
+import signal
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T = 512 * 512  # the CLI always runs the reference's 512 x 512 threads (cudabrot.cu:20,23)
+
+
+@pytest.fixture(scope="module")
+def exe(repo_root):
+    path = os.path.join(repo_root, "cudabrot")
+    assert os.access(path, os.X_OK), "./cudabrot is not built"
+    return path
+
+
+def run(exe, *args, **kw):
+    return subprocess.run([exe, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, **kw)
+
+
+@pytest.fixture(scope="module")
+def small_render(oracle):
+    """Oracle result of `--passes 2 -w 300 -h 200 -m 200` (all host cores; same multiset of samples)."""
+    hist, cnt = oracle.render(300, 200, 200, 20, T, 2, omp_threads=0)
+    return hist, cnt
+
+
+def test_fixed_pass_run_matches_oracle_byte_for_byte(exe, oracle, small_render, tmp_path):
+    out, buf = str(tmp_path / "o.pgm"), str(tmp_path / "state.bin")
+    r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-g", "2.2", "-o", out, "-s", buf)
+    assert r.returncode == 0 and r.stderr == ""
+    hist, _ = small_render
+    gray, mx, scale = oracle.set_grayscale_pixels(hist, 2.2)
+    lines = r.stdout.split("\n")
+    # the reference's stdout sequence
+    assert lines[0] == "Creating 300x200 image, 200 max iterations."
+    assert lines[1] == "Calculating image..."
+    assert lines[2].startswith("Approximate memory needed: ")
+    assert lines[3] == "Loading previous image state from %s." % buf
+    assert lines[4] == "File %s doesn't exist yet. Not loading." % buf
+    assert lines[5] == "Calculating Buddhabrot."
+    assert re.fullmatch(r"2 Buddhabrot passes took [0-9.]+ seconds\.", lines[6])
+    assert lines[7] == "Max value: %d, scale: %f" % (mx, scale)
+    assert lines[8] == "Saving in-progress buffer to %s." % buf
+    assert lines[9] == "Saving image."
+    assert lines[10] == "Done! Output image saved: %s" % out
+    with open(out, "rb") as f:
+        assert f.read() == oracle.encode_pgm(gray)
+    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)   # raw native-endian u64[h][w]
+    assert np.array_equal(state, hist)
+
+
+def test_resume_adds_to_the_saved_buffer(exe, small_render, tmp_path):
+    """-s: load, render ON TOP, save (cudabrot.cu:783-785).  The generator restarts from seed 1337
+    (SURVEY.md F5), so a second identical run doubles every count."""
+    buf = str(tmp_path / "state.bin")
+    args = ["--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf]
+    assert run(exe, *args).returncode == 0
+    r = run(exe, *args)
+    assert r.returncode == 0
+    assert "doesn't exist yet" not in r.stdout
+    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)
+    assert np.array_equal(state, 2 * small_render[0])
+
+
+def test_reference_format_u32_buffer_is_accepted_and_widened(exe, small_render, tmp_path):
+    buf = str(tmp_path / "ref_state.bin")
+    base = (np.arange(300 * 200, dtype=np.uint32) % 1000).reshape(200, 300)
+    base.tofile(buf)                                   # what the reference writes: uint32[h][w]
+    r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 0
+    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)   # rewritten as u64
+    assert np.array_equal(state, base.astype(np.uint64) + small_render[0])
+
+
+def test_buffer_size_mismatch_is_an_error(exe, tmp_path):
+    buf = str(tmp_path / "bad.bin")
+    with open(buf, "wb") as f:
+        f.write(b"\0" * 1000)
+    r = run(exe, "--passes", "1", "-w", "300", "-h", "200", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 1                                           # cudabrot.cu:239-245
+    assert "The size of %s doesn't match the expected size of %d bytes." % (buf, 300 * 200 * 8) in r.stdout
+    assert os.path.getsize(buf) == 1000                                # left untouched
+
+
+@pytest.mark.parametrize("gamma", ["1.0", "0", "-1", "0.5"])
+def test_gamma_variants(exe, oracle, small_render, tmp_path, gamma):
+    out = str(tmp_path / "g.pgm")
+    r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-g", gamma, "-o", out)
+    assert r.returncode == 0
+    gray, _, _ = oracle.set_grayscale_pixels(small_render[0], float(gamma))
+    with open(out, "rb") as f:
+        assert f.read() == oracle.encode_pgm(gray)
+
+
+def test_timed_run_renders_at_least_one_pass_and_stops(exe, tmp_path):
+    out = str(tmp_path / "t.pgm")
+    t0 = time.time()
+    r = run(exe, "-t", "0.5", "-w", "256", "-h", "256", "-o", out)
+    assert r.returncode == 0
+    assert "Running for 0.500 seconds." in r.stdout
+    m = re.search(r"(\d+) Buddhabrot passes took ([0-9.]+) seconds", r.stdout)
+    assert m and int(m.group(1)) >= 1 and 0.5 <= float(m.group(2)) < 5.0
+    assert time.time() - t0 < 60
+    with open(out, "rb") as f:
+        assert f.read(15) == b"P5\n256 256\n6553"
+
+
+def test_sigint_finishes_the_pass_and_still_saves(exe, tmp_path):
+    """-t < 0 runs until SIGINT; the handler lets the current launch finish, the image and the -s buffer
+    are written and the exit code is 0 (cudabrot.cu:475-476, 756-760)."""
+    out, buf = str(tmp_path / "i.pgm"), str(tmp_path / "i.bin")
+    p = subprocess.Popen([exe, "-t", "-1", "-w", "256", "-h", "256", "-o", out, "-s", buf],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(3.0)
+    p.send_signal(signal.SIGINT)
+    stdout, _ = p.communicate(timeout=120)
+    assert p.returncode == 0
+    assert "Press ctrl+C to finish." in stdout
+    assert "Signal 2 received, waiting for current pass to finish..." in stdout
+    assert "Done! Output image saved: %s" % out in stdout
+    assert os.path.getsize(out) == len(b"P5\n256 256\n65535\n") + 256 * 256 * 2
+    assert os.path.getsize(buf) == 256 * 256 * 8
+
+
+def test_invalid_device_reports_like_the_reference_and_exits_one(exe):
+    r = run(exe, "-d", "99", "--passes", "1", "-w", "16", "-h", "16", "-o", os.devnull)
+    assert r.returncode == 1
+    assert r.stdout.strip().split("\n")[-1].startswith("CUDA error ")   # cudabrot.cu:137, wording kept

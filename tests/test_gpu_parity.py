@@ -173,6 +173,20 @@ def test_direct_atomics_mode_equals_binned_mode(cb, oracle, cfg, monkeypatch):
     assert_same(binned, cpu)
 
 
+def test_periodicity_early_out_changes_nothing_but_the_work(cb, oracle):
+    """Orbits found exactly periodic are retired early: same histogram and the same
+    reference-side counters as iterating every sample to max_iter, with most iterations not executed."""
+    cfg = dict(w=512, h=512, max_iter=20000, min_iter=20, threads=8192, passes=2)
+    early = gpu_render(cb, **cfg)
+    full = gpu_render(cb, variant=cb.CB_KERNEL_FULL_ITERATE, **cfg)
+    cpu = oracle.render(cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"])
+    assert_same(early, cpu)
+    assert_same(full, cpu)
+    assert full[1]["skipped_steps"] == 0
+    assert 0 < early[1]["skipped_steps"] <= early[1]["never_escaped"] * cfg["max_iter"]
+    assert early[1]["skipped_steps"] > 0.5 * early[1]["iterate_steps"]   # deep orbits: most work is skipped
+
+
 def _torch_render(cb, w, h, max_iter, min_iter, t, passes, workspace_bytes, box=BOX):
     import torch
 
