@@ -79,7 +79,7 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.h = dims->h;
   a.max_iter = it->max_escape_iterations;
   a.min_iter = it->min_escape_iterations;
-  a.head_steps = cb::choose_head_steps(a.max_iter, a.min_iter);
+  cb::plan_stages(a.max_iter, a.min_iter, &a.head_steps, &a.mid_steps);
   a.n_threads = n_threads;
   a.samples_per_thread = samples_per_thread;
   a.hist = reinterpret_cast<unsigned long long *>(d_hist);
@@ -256,7 +256,11 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
   if (!r) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));
   // 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
-  const uint32_t max_passes_per_launch = kRendererPassesPerLaunch;
+  static const uint32_t max_passes_per_launch = [] {
+    const char *e = getenv("CUDABROT_AMD_PASSES_PER_LAUNCH");  // experiment knob
+    const long v = e ? atol(e) : 0;
+    return (v >= 1 && v <= 4096) ? (uint32_t) v : kRendererPassesPerLaunch;
+  }();
   if (kernel_variant == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") && !g_wave_dump) {
     const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
     if (hipMalloc(&g_wave_dump, bytes) != hipSuccess || hipMemset(g_wave_dump, 0, bytes) != hipSuccess) {

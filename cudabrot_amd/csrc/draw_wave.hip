@@ -1,0 +1,793 @@
+// draw_wave.hip -- draw_wave_kernel, the product path of DrawBuddhabrot (cudabrot.cu:379-414).
+//
+// Compiled with -ffp-contract=off (device_math.h).  wave = 64 lanes everywhere.
+//
+// Why this shape.  At max_iter = 20000 a sample needs 168 iterations on average, but 89 % of the
+// samples need < 20 and 0.8 % need all 20000: one lane per reference thread in lock-step keeps ~2 % of
+// the lanes busy (that is draw_simple_kernel and the reference itself).  Histogram
+// increments commute, so ANY schedule of the fixed multiset of samples {(subsequence t, sample n)}
+// gives the identical histogram, provided each subsequence is consumed in order with exactly four
+// draws per sample.  Each wave therefore owns 64 subsequences (lane l of wave v is reference thread
+// 64 v + l, as in the reference) and runs four stages over them, decoupled by three wave-private
+// queues in LDS (no barriers: a wave's LDS operations are in order):
+//
+//   HEAD    all 64 lanes draw a starting point (4 XORWOW outputs, registers only), apply the
+//           cardioid / bulb test and run the first head_steps (4) iterations under the EXEC mask.
+//           Survivors (~20 %) are ballot-compacted into Q0 as c.
+//   MID     64 survivors at a time run the next mid_steps (12..43) iterations in lock-step, dense:
+//           this is where the many orbits that leave after a few dozen iterations leave.  mid_steps
+//           is chosen so that min_iter - (head_steps + mid_steps) is a multiple of kChunk.
+//           Survivors (~2 % of the samples) go to Q1 as (c, z).
+//   LONG    each lane holds TWO deep orbits and iterates them side by side in chunks of kChunk (32)
+//           steps of hand-written asm; finished slots refill from Q1 at chunk boundaries, so the lanes
+//           stay on deep orbits.  An orbit is retired when it escapes, reaches max_iter, or is found
+//           to be exactly periodic (then it can never escape).  Escaped orbits whose chunk lies at or
+//           above min_iter go to Q2 as c.  No chunk straddles min_iter (the MID alignment), so
+//           "which chunk" decides accept / too-fast exactly although the escape index inside the
+//           chunk is not known; a last, shorter chunk before max_iter runs in a counted loop.
+//   REPLAY  each lane pops one accepted starting point from Q2, re-iterates it from z0 = c with the
+//           same step and records every visited point (asm burst into the pixel stream, or direct
+//           device-scope u64 atomics without a workspace).  Lanes refill from Q2 as they finish; a
+//           replay in flight is suspended (state stays in registers) while too few lanes are busy.
+//
+// All step loops are hand-written gfx950 assembly: per iteration 7 fp64 VALU instructions + one
+// compare and 2-3 scalar instructions for the exact lane-step count.  The compiler's own lowering of
+// the same loops spent ~35 scalar instructions per step on mask bookkeeping, and the one scalar
+// unit of a CU serves all four SIMDs.
+#include <stdlib.h>
+
+#include "draw_common.h"
+
+namespace cb {
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kOrbitsPerLane = 2;      // deep orbits a lane iterates side by side in the LONG stage
+constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
+constexpr int kQ1Cap = 128;            // MID survivors: (c, z)        (4 KiB per wave)
+constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
+constexpr int kQ1Low = 16;             // run MID while fewer deep orbits than this are queued
+constexpr int kReplayMin = 32;         // suspend REPLAY below this many busy lanes (unless draining)
+constexpr uint32_t kReplayBurst = 8;   // replay steps per asm burst
+constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
+
+struct WaveQueues {
+  double q0_cr[kQ0Cap], q0_ci[kQ0Cap];
+  double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];
+  double q2_cr[kQ2Cap], q2_ci[kQ2Cap];
+};
+
+struct Orbit {
+  double cr, ci, r, i;
+};
+
+__device__ __forceinline__ bool lane_in(unsigned long long mask) {
+  return (mask >> lane_id()) & 1ull;
+}
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+  return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+  return __longlong_as_double((long long) uniform_u64((unsigned long long) __double_as_longlong(v)));
+}
+
+// ---- one orbit per lane under EXEC (HEAD, MID, the last short chunk of LONG) -----------------------
+//
+// One z <- z^2 + c step on the lanes in EXEC, in the canonical order of device_math.h's mandel_step:
+//   a = i*i; b = r+r; a = fma(r,r,-a); i = fma(b,i,ci); r = cr + a; a = r*r; a = fma(i,i,a)
+// then EXEC &= !(4.0 < a) (v_cmpx: a lane leaves at its escape, cudabrot.cu:336), after adding the
+// number of lanes that execute the step to the scalar counter.
+#define CB_STEP                                       \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "v_add_f64 %[b], %[r], %[r]\n\t"                    \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"             \
+  "v_add_f64 %[r], %[cr], %[a]\n\t"                   \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, 4.0, %[a]\n\t"
+
+// n steps (wave-uniform run-time count) on the lanes of `mask`, leaving early once every lane has
+// escaped.  Returns the lanes that escaped; r, i of the others advance by n iterations; lane_steps
+// receives the executed lane-steps (a lane that escapes at its j-th step counts j).
+__device__ __forceinline__ unsigned long long iterate_steps(unsigned long long mask, uint32_t n,
+                                                            Orbit &o, uint32_t &lane_steps) {
+  unsigned long long save, escaped;
+  uint32_t cnt, tmp, ctr;
+  double a, b;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "1:\n\t"
+      CB_STEP
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_andn2_b64 %[esc], %[mask], exec\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [r] "+v"(o.r), [i] "+v"(o.i), [a] "=&v"(a), [b] "=&v"(b), [save] "=&s"(save),
+        [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr)
+      : [mask] "s"(mask), [n] "s"(n), [cr] "v"(o.cr), [ci] "v"(o.ci)
+      : "vcc", "scc");
+  lane_steps = cnt;
+  return escaped;
+}
+
+// Runs iterations [k0, k0 + n) of the orbits in `alive` (IterateMandelbrot, cudabrot.cu:326-337) and
+// sorts the escapes by the accept filter of cudabrot.cu:407-408: an escape at index k < min_iter is
+// too fast, one at k >= min_iter is accepted (k < max_iter holds by construction).  Removes the
+// escaped lanes from `alive`; returns the accepted ones.
+__device__ __forceinline__ unsigned long long iterate_window(unsigned long long &alive, int k0, int n,
+                                                             int min_iter, Orbit &o,
+                                                             unsigned long long &n_iterate,
+                                                             unsigned long long &n_too_fast) {
+  int n_fast = min_iter - k0;  // leading steps whose escapes are too fast
+  n_fast = n_fast < 0 ? 0 : (n_fast > n ? n : n_fast);
+  uint32_t steps = 0;
+  if (alive != 0ull && n_fast != 0) {
+    const unsigned long long esc = iterate_steps(alive, (uint32_t) n_fast, o, steps);
+    n_iterate += steps;
+    n_too_fast += (unsigned long long) __popcll(esc);
+    alive &= ~esc;
+  }
+  unsigned long long accepted = 0ull;
+  if (alive != 0ull && n - n_fast != 0) {
+    accepted = iterate_steps(alive, (uint32_t) (n - n_fast), o, steps);
+    n_iterate += steps;
+    alive &= ~accepted;
+  }
+  return accepted;
+}
+
+// ---- two orbits per lane, EXEC untouched (LONG) ----------------------------------------------------
+//
+// The LONG stage keeps TWO independent orbits (A and B) per lane and interleaves them instruction by
+// instruction: the step is a chain of ~6 dependent fp64 operations, and a SIMD whose waves drift
+// apart must be able to fill the fp64 pipe from few waves.  Measured with this very chunk on MI355X
+// (tools/microbench.hip): 84.5 % of fp64 issue peak at 4 waves per SIMD, 60 % from a single wave
+// (one orbit per lane: 58 % / 32 %).
+//
+// Two orbit sets cannot share one EXEC mask, so EXEC stays untouched: every lane computes every
+// step (an idle or already escaped slot computes garbage that nothing reads) and the orbits still
+// iterating are tracked in two scalar masks, la and lb: la &= !(4.0 < |zA|^2) after each step
+// (cudabrot.cu:336).  The and for step n is issued inside step n+1, behind its first VALU
+// instructions, so that the scalar unit never waits for the compare.  cnt += popcount(la) +
+// popcount(lb) before each step keeps the exact count of iterations the reference would execute.
+// Same instruction order per orbit as CB_STEP / mandel_step.
+#define CB_STEP2                                          \
+  "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
+  "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
+  "s_and_b64 %[la], %[la], %[c0]\n\t"                     \
+  "v_add_f64 %[b0], %[ra], %[ra]\n\t"                     \
+  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
+  "v_add_f64 %[b1], %[rb], %[rb]\n\t"                     \
+  "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
+  "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
+  "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
+  "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
+  "s_add_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
+  "v_fma_f64 %[ia], %[b0], %[ia], %[cia]\n\t"             \
+  "s_add_u32 %[cnt], %[cnt], %[t1]\n\t"                   \
+  "v_fma_f64 %[ib], %[b1], %[ib], %[cib]\n\t"             \
+  "v_add_f64 %[ra], %[cra], %[a0]\n\t"                    \
+  "v_add_f64 %[rb], %[crb], %[a1]\n\t"                    \
+  "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
+  "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
+  "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
+  "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
+  "v_cmp_nlt_f64_e64 %[c0], 4.0, %[a0]\n\t"               \
+  "v_cmp_nlt_f64_e64 %[c1], 4.0, %[a1]\n\t"
+#define CB_STEP2X4 CB_STEP2 CB_STEP2 CB_STEP2 CB_STEP2
+#define CB_STEP2X32 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+
+// kChunk steps on orbit A of the lanes in mask_a and on orbit B of the lanes in mask_b (both
+// wave-uniform; called with EXEC = all 64 lanes).  esc_a / esc_b receive the lanes whose orbit
+// escaped; the other orbits of the masks advance by kChunk iterations; lane_steps receives the
+// executed lane-steps.  z of slots outside the masks is clobbered.
+__device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsigned long long mask_b,
+                                               Orbit &oa, Orbit &ob, unsigned long long &esc_a,
+                                               unsigned long long &esc_b, uint32_t &lane_steps) {
+  static_assert(kChunk == 32, "CB_STEP2X32 is unrolled for 32 steps");
+  unsigned long long la = mask_a, lb = mask_b, c0, c1;
+  uint32_t cnt, t0, t1;
+  double a0, a1, b0, b1;
+  asm volatile(
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 %[c0], -1\n\t"
+      "s_mov_b64 %[c1], -1\n\t"
+      CB_STEP2X32
+      "s_and_b64 %[la], %[la], %[c0]\n\t"
+      "s_and_b64 %[lb], %[lb], %[c1]\n\t"
+      : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [la] "+s"(la),
+        [lb] "+s"(lb), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+        [c0] "=&s"(c0), [c1] "=&s"(c1), [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)
+      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci)
+      : "scc");
+  esc_a = mask_a & ~la;
+  esc_b = mask_b & ~lb;
+  lane_steps = cnt;
+}
+
+// ---- REPLAY burst: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream --------------------
+//
+// One step for the lanes of `act` (EXEC), in the order of the reference's loop body:
+//   z <- z^2 + c            (CB_STEP's seven fp64 instructions, same order)
+//   IncrementPixelCounter   if (re >= min_re && im >= min_im) { col = (int)((re-min_re)/d_re); row
+//                           likewise; if (col <u w && row <u h) append row<<16|col to the stream }
+//                           (cudabrot.cu:308-312; the unsigned compares also reject the saturated
+//                           conversions, and col, row cannot be negative past the first test)
+//   if (|z|^2 > 4) leave    (cudabrot.cu:363) -- after recording the escaped point, like the reference
+// The hits of a step are compacted with v_mbcnt and stored side by side (one coalesced store).
+// x / delta: an exact multiply when both deltas are powers of two (CB_REPLAY_BIN_POW2), else the
+// correctly rounded IEEE quotient by the same instruction sequence hipcc emits for a double
+// division (CB_REPLAY_BIN_DIV: v_div_scale / v_rcp / Newton steps / v_div_fmas / v_div_fixup).
+#define CB_REPLAY_BIN_POW2                                \
+  "v_mul_f64 %[fx], %[fx], %[sx]\n\t"                     \
+  "v_mul_f64 %[fy], %[fy], %[sy]\n\t"
+#define CB_DIV(q, num, den)                                         \
+  "v_div_scale_f64 %[d0], %[scp], " den ", " den ", " num "\n\t"    \
+  "v_rcp_f64 %[d2], %[d0]\n\t"                                      \
+  "v_div_scale_f64 %[d1], vcc, " num ", " den ", " num "\n\t"       \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_mul_f64 %[d3], %[d1], %[d2]\n\t"                               \
+  "v_fma_f64 %[d0], -%[d0], %[d3], %[d1]\n\t"                       \
+  "v_div_fmas_f64 %[d0], %[d0], %[d2], %[d3]\n\t"                   \
+  "v_div_fixup_f64 " q ", %[d0], " den ", " num "\n\t"
+#define CB_REPLAY_BIN_DIV CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]")
+
+#define CB_REPLAY_HEAD                                    \
+  "s_mov_b64 %[save], exec\n\t"                           \
+  "s_mov_b32 %[cs], 0\n\t"                                \
+  "s_mov_b32 %[ch], 0\n\t"                                \
+  "s_mov_b32 %[ctr], %[n]\n\t"                            \
+  "1:\n\t"                                                \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
+  "v_add_f64 %[b], %[r], %[r]\n\t"                        \
+  "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
+  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"                 \
+  "v_add_f64 %[r], %[cr], %[a]\n\t"                       \
+  "v_add_u32 %[ps], 1, %[ps]\n\t"                         \
+  "v_add_f64 %[fy], %[i], -%[miny]\n\t"                   \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_add_f64 %[fx], %[r], -%[minx]\n\t"                   \
+  "v_cmp_le_f64_e64 %[hy], %[miny], %[i]\n\t"             \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "v_cmp_le_f64_e64 %[hx], %[minx], %[r]\n\t"
+#define CB_REPLAY_TAIL                                    \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_cmp_nlt_f64_e64 %[alive], 4.0, %[a]\n\t"             \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
+  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
+  "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"         \
+  "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_cmp_eq_u64 %[act], 0\n\t"                            \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
+  "s_cbranch_scc1 1b\n\t"                                 \
+  "2:\n\t"                                                \
+  "s_mov_b64 exec, %[save]\n\t"                           \
+  "s_nop 4\n\t"
+
+// Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for
+// 64 * n_steps more entries.  On return `act` holds the lanes still replaying, `fill` the new fill,
+// lane_steps / hits the executed lane-steps and the entries appended.
+template <bool kPow2>
+__device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
+                                             int &p_steps, const Canvas &cv, uint32_t *region,
+                                             uint32_t &fill, uint32_t &lane_steps, uint32_t &hits) {
+  unsigned long long save, alive, hx, hy, scp;
+  uint32_t cs, ch, ctr, t;
+  double a, b, fx, fy, d0, d1, d2, d3;
+  uint32_t col, row, pidx, e;
+  // x / delta as an exact multiply (kPow2) or a true division: the scale operands.  All "s"
+  // operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
+  const double sx = uniform_f64(kPow2 ? cv.inv_delta_real : cv.delta_real);
+  const double sy = uniform_f64(kPow2 ? cv.inv_delta_imag : cv.delta_imag);
+  const double minx = uniform_f64(cv.min_real), miny = uniform_f64(cv.min_imag);
+  const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t) cv.w);
+  const uint32_t h = __builtin_amdgcn_readfirstlane((uint32_t) cv.h);
+  region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
+  act = uniform_u64(act);
+  fill = __builtin_amdgcn_readfirstlane(fill);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  if (kPow2) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
+                   [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
+                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
+                   [base] "s"(region)
+                 : "vcc", "scc", "memory");
+  } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
+                   [a] "=&v"(a), [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
+                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
+                   [base] "s"(region)
+                 : "vcc", "scc", "memory");
+  }
+  lane_steps = cs;
+  hits = ch;
+}
+
+// ring index helper for the 192-entry Q2
+__device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
+
+template <bool kTimed, bool kBinned>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs a) {
+  static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
+  __shared__ WaveQueues queues[kWavesPerBlock];
+  WaveQueues &q = queues[threadIdx.x >> 6];
+
+  // kBinned: this wave's region of the pixel stream (kernels.h, BinLayout)
+  const uint32_t wave_id =
+      __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  uint32_t *const region = kBinned ? a.bin.stream + (size_t) wave_id * a.bin.cap : nullptr;
+  const uint32_t region_cap = kBinned ? a.bin.cap : 0u;
+  uint32_t region_fill = 0;
+
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = tid < a.n_threads;
+  const unsigned long long valid_mask = __ballot(valid);
+  const Canvas cv = make_canvas(a);
+  const int max_iter = a.max_iter;
+  const int min_iter = a.min_iter;
+  const int head_steps = a.head_steps;                          // HEAD runs iterations [0, head_steps)
+  const int mid_steps = a.mid_steps;                            // MID runs [head_steps, long_start)
+  const int long_start = head_steps + mid_steps;                // <= max_iter
+  const int long_steps = max_iter - long_start;                 // iterations left to the LONG stage
+  const int tail_steps = long_steps % kChunk;                   // an orbit's last, shorter chunk
+
+  Xorwow rng = {0, 0, 0, 0, 0, 0};
+  if (valid) rng = load_rng(a.states, a.n_threads, tid);
+
+  // wave-uniform scheduler state and statistics (scalar registers)
+  uint32_t samples_left = a.samples_per_thread;
+  int q0_head = 0, q0_count = 0;
+  int q1_head = 0, q1_count = 0;
+  int q2_head = 0, q2_count = 0;
+  unsigned long long n_rejected = 0, n_never = 0, n_too_fast = 0, n_recorded = 0, n_iterate = 0,
+                     n_replay = 0, n_incr = 0, status = 0;
+  unsigned long long t_head = 0, t_long = 0, t_replay = 0, dbg_chunks = 0, dbg_slots = 0;
+  const unsigned long long t_start = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_start = kTimed ? __builtin_amdgcn_s_memrealtime() : 0ull;
+
+  // wave slot on its SIMD (HW_REG_HW_ID bits 3:0) and chunks done, for the priority rotation
+  const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));
+  uint32_t long_chunks = 0;
+  // LONG lane state: two orbits per lane (see CB_STEP2)
+  Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
+  int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
+  unsigned long long skipped_steps = 0;  // per lane: iterations the periodicity check made unnecessary
+  // REPLAY lane state
+  Orbit po = {0, 0, 0, 0};
+  bool p_act = false;
+  int p_steps = 0;
+
+  for (;;) {
+    const bool input_done = (samples_left == 0);
+    const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0) != 0ull;
+    const bool draining = input_done && (q0_count == 0) && (q1_count == 0) && !l_any;
+    const int n_replaying = __popcll(__ballot(p_act));
+
+    // ---------------------------------------------------------------- REPLAY
+    if ((q2_count > 0 && q2_count + n_replaying >= 64) ||
+        (draining && (q2_count > 0 || n_replaying > 0))) {
+      const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+      for (;;) {
+        {  // refill idle lanes from Q2
+          const unsigned long long idle_mask = __ballot(!p_act);
+          const int n_idle = __popcll(idle_mask);
+          const int n = n_idle < q2_count ? n_idle : q2_count;
+          if (n > 0) {
+            const int rank = mask_prefix(idle_mask);
+            if (!p_act && rank < n) {
+              const int slot = q2_wrap(q2_head + rank);
+              po.cr = q.q2_cr[slot];
+              po.ci = q.q2_ci[slot];
+              po.r = po.cr;
+              po.i = po.ci;
+              p_steps = 0;
+              p_act = true;
+            }
+            q2_head = q2_wrap(q2_head + n);
+            q2_count -= n;
+            n_recorded += (unsigned long long) n;
+          }
+        }
+        const int n_act = __popcll(__ballot(p_act));
+        if (n_act == 0) break;
+        if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
+
+        // kBinned: the visited pixels go to this wave's stream region (compacted, coalesced stores)
+        // in a hand-written burst; a full region falls back to the direct-atomics loop below, so
+        // the result never depends on the workspace size.
+        if (kBinned && region_fill + 64u * kReplayBurst <= region_cap) {
+          unsigned long long act_mask = __ballot(p_act);
+          uint32_t steps = 0, hits = 0;
+          if (cv.pow2_real && cv.pow2_imag) {
+            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+          } else {
+            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+          }
+          n_replay += steps;
+          n_incr += hits;
+          p_act = lane_in(act_mask);
+          if (__ballot(p_act && p_steps > max_iter) != 0ull) {
+            // cannot happen: the orbit escaped within max_iter steps in an earlier stage
+            status |= CB_STATUS_REPLAY_RUNAWAY;
+            if (p_steps > max_iter) p_act = false;
+          }
+          continue;
+        }
+        for (uint32_t b = 0; b < kReplayBurst; ++b) {
+          const unsigned long long act_mask = __ballot(p_act);
+          if (act_mask == 0ull) break;
+          n_replay += (unsigned long long) __popcll(act_mask);
+          bool done = false, hit = false;
+          int row = 0, col = 0;
+          if (p_act) {
+            const double m = mandel_step(po.cr, po.ci, po.r, po.i);   // cudabrot.cu:357-359
+            hit = pixel_of(po.r, po.i, cv, row, col);                 // cudabrot.cu:308-311
+            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);        // cudabrot.cu:312
+            p_steps++;
+            done = m > 4.0;                                           // cudabrot.cu:363
+            if (!done && p_steps > max_iter) {
+              status |= CB_STATUS_REPLAY_RUNAWAY;
+              done = true;
+            }
+            if (done) p_act = false;
+          }
+          n_incr += (unsigned long long) __popcll(__ballot(hit));
+          if (__ballot(done) != 0ull && q2_count > 0) break;
+        }
+      }
+      if (kTimed) t_replay += __builtin_amdgcn_s_memtime() - t0;
+      if (draining) break;
+      continue;
+    }
+    if (draining) break;
+
+    // ---------------------------------------------------------------- HEAD
+    if (!input_done && q0_count < 64) {
+      const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+      samples_left--;
+      bool alive = false;
+      Orbit o = {0, 0, 0, 0};
+      if (valid) {
+        o.cr = sample_coordinate(rng);  // cudabrot.cu:392
+        o.ci = sample_coordinate(rng);  // cudabrot.cu:393
+        alive = !(in_main_cardioid(o.cr, o.ci) || in_order2_bulb(o.cr, o.ci));  // cudabrot.cu:398
+      }
+      o.r = o.cr;
+      o.i = o.ci;
+      unsigned long long alive_mask = __ballot(alive);
+      n_rejected += (unsigned long long) __popcll(valid_mask & ~alive_mask);
+      const unsigned long long accept_mask =
+          iterate_window(alive_mask, 0, head_steps, min_iter, o, n_iterate, n_too_fast);
+      if (accept_mask != 0ull) {
+        if (lane_in(accept_mask)) {
+          const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(accept_mask));
+          q.q2_cr[slot] = o.cr;
+          q.q2_ci[slot] = o.ci;
+        }
+        q2_count += __popcll(accept_mask);
+        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+      }
+      if (alive_mask != 0ull) {  // survivors of the head
+        if (max_iter > head_steps) {
+          if (lane_in(alive_mask)) {
+            const int slot = (q0_head + q0_count + mask_prefix(alive_mask)) & (kQ0Cap - 1);
+            q.q0_cr[slot] = o.cr;
+            q.q0_ci[slot] = o.ci;
+          }
+          q0_count += __popcll(alive_mask);
+          if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        } else {
+          n_never += (unsigned long long) __popcll(alive_mask);  // head_steps == max_iter
+        }
+      }
+      if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
+      continue;
+    }
+
+    // ---------------------------------------------------------------- MID
+    if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || input_done)) {
+      const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+      const int n = q0_count < 64 ? q0_count : 64;
+      const bool mine = lane_id() < n;
+      Orbit o = {0, 0, 0, 0};
+      if (mine) {
+        const int slot = (q0_head + lane_id()) & (kQ0Cap - 1);
+        o.cr = q.q0_cr[slot];
+        o.ci = q.q0_ci[slot];
+      }
+      o.r = o.cr;
+      o.i = o.ci;
+      q0_head = (q0_head + n) & (kQ0Cap - 1);
+      q0_count -= n;
+      unsigned long long alive_mask = __ballot(mine);
+      {  // re-derive z after the head iterations (Q0 keeps only c); none of these can escape again
+        uint32_t ignored = 0;
+        (void) iterate_steps(alive_mask, (uint32_t) head_steps, o, ignored);
+      }
+      const unsigned long long accept_mask =
+          iterate_window(alive_mask, head_steps, mid_steps, min_iter, o, n_iterate, n_too_fast);
+      if (accept_mask != 0ull) {
+        if (lane_in(accept_mask)) {
+          const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(accept_mask));
+          q.q2_cr[slot] = o.cr;
+          q.q2_ci[slot] = o.ci;
+        }
+        q2_count += __popcll(accept_mask);
+        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+      }
+      if (alive_mask != 0ull) {  // survivors of the mid stage
+        if (long_steps > 0) {
+          if (lane_in(alive_mask)) {
+            const int slot = (q1_head + q1_count + mask_prefix(alive_mask)) & (kQ1Cap - 1);
+            q.q1_cr[slot] = o.cr;
+            q.q1_ci[slot] = o.ci;
+            q.q1_r[slot] = o.r;
+            q.q1_i[slot] = o.i;
+          }
+          q1_count += __popcll(alive_mask);
+          if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        } else {
+          n_never += (unsigned long long) __popcll(alive_mask);  // long_start == max_iter
+        }
+      }
+      if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
+      continue;
+    }
+
+    // ---------------------------------------------------------------- LONG
+    const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+    for (;;) {
+      // Even progress for the waves of a SIMD.  VALU issue goes by priority, then by wave age, so
+      // with equal priorities the oldest wave races ahead and the youngest is left to finish alone,
+      // where one wave cannot fill the fp64 pipe (measured: the 4 waves of a SIMD ended at 31 / 40 /
+      // 53 / 65 ms of a 65 ms kernel).  Each wave therefore walks through the four priority levels
+      // as it progresses, offset by its wave slot.
+      if ((long_chunks & (kPrioChunks - 1u)) == 0u) {
+        switch ((wave_slot + long_chunks / kPrioChunks) & 3u) {
+          case 0: __builtin_amdgcn_s_setprio(0); break;
+          case 1: __builtin_amdgcn_s_setprio(1); break;
+          case 2: __builtin_amdgcn_s_setprio(2); break;
+          default: __builtin_amdgcn_s_setprio(3); break;
+        }
+      }
+      ++long_chunks;
+      unsigned long long full_mask[kOrbitsPerLane], tail_mask[kOrbitsPerLane], esc[kOrbitsPerLane];
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {  // refill idle orbit slots from Q1
+        const unsigned long long idle_mask = __ballot(l_rem[o] == 0);
+        if (idle_mask != 0ull && q1_count > 0) {
+          const int n_idle = __popcll(idle_mask);
+          const int n = n_idle < q1_count ? n_idle : q1_count;
+          const int rank = mask_prefix(idle_mask);
+          if (l_rem[o] == 0 && rank < n) {
+            const int slot = (q1_head + rank) & (kQ1Cap - 1);
+            lo[o].cr = q.q1_cr[slot];
+            lo[o].ci = q.q1_ci[slot];
+            lo[o].r = q.q1_r[slot];
+            lo[o].i = q.q1_i[slot];
+            l_rem[o] = long_steps;
+            seen_r[o] = lo[o].r;  // periodicity check: first saved point = the entry point
+            seen_i[o] = lo[o].i;
+          }
+          q1_head = (q1_head + n) & (kQ1Cap - 1);
+          q1_count -= n;
+        }
+        full_mask[o] = __ballot(l_rem[o] >= kChunk);
+        tail_mask[o] = (tail_steps != 0) ? __ballot(l_rem[o] > 0 && l_rem[o] < kChunk) : 0ull;
+        esc[o] = 0ull;
+      }
+      if ((full_mask[0] | full_mask[1] | tail_mask[0] | tail_mask[1]) == 0ull) break;
+
+      uint32_t steps = 0;
+      if ((tail_mask[0] | tail_mask[1]) != 0ull) {
+#pragma unroll
+        for (int o = 0; o < kOrbitsPerLane; ++o) {
+          if (tail_mask[o] != 0ull) {  // last, shorter chunk of these orbits: exactly tail_steps iterations
+            esc[o] = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o], steps);
+            n_iterate += steps;
+            n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc[o]);
+          }
+        }
+      }
+      if ((full_mask[0] | full_mask[1]) != 0ull) {
+        unsigned long long e0, e1;
+        iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], e0, e1, steps);
+        esc[0] |= e0;
+        esc[1] |= e1;
+        n_iterate += steps;
+        if (kTimed) {
+          dbg_chunks++;
+          dbg_slots += (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
+        }
+      }
+      // Bookkeeping.  An orbit's chunk covered escape indices [k_lo, k_lo + chunk length) with
+      // k_lo = max_iter - l_rem; min_iter - long_start is a multiple of kChunk, so the whole chunk is
+      // on one side of min_iter (cudabrot.cu:407-408).
+#pragma unroll
+      for (int o = 0; o < kOrbitsPerLane; ++o) {
+        const bool in_full = lane_in(full_mask[o]);
+        if ((esc[o] | tail_mask[o]) != 0ull) {  // something ended in this chunk
+          const bool escaped = lane_in(esc[o]);
+          const bool push = escaped && (max_iter - l_rem[o] >= min_iter);
+          n_too_fast += (unsigned long long) __popcll(esc[o] & ~__ballot(push));
+          if (escaped || lane_in(tail_mask[o])) l_rem[o] = 0;
+          const unsigned long long push_mask = __ballot(push);
+          if (push_mask != 0ull) {
+            if (push) {
+              const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(push_mask));
+              q.q2_cr[slot] = lo[o].cr;
+              q.q2_ci[slot] = lo[o].ci;
+            }
+            q2_count += __popcll(push_mask);
+            if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+          }
+        }
+        // orbits that went through the whole chunk without escaping
+        bool ended = false;
+        if (in_full && l_rem[o] >= kChunk) {
+          l_rem[o] -= kChunk;
+          ended = (l_rem[o] == 0);  // reached max_iter: IterateMandelbrot returns max (cudabrot.cu:339)
+          // Exact-periodicity early-out.  If z is bit for bit a value this orbit
+          // held at an earlier chunk boundary, the (deterministic) orbit repeats that stretch for
+          // ever and every point of the stretch passed the escape test: the sample can never
+          // escape, so IterateMandelbrot would return max_iterations -- the same outcome, without
+          // executing the remaining iterations.  Brent's scheme at chunk granularity: compare with
+          // one saved point, re-save when the chunk count is a power of two; a cycle of period p is
+          // found at most kChunk * p iterations after it has begun.
+          const bool periodic = (a.check_periodic != 0) && !ended &&
+                                (__double_as_longlong(lo[o].r) == __double_as_longlong(seen_r[o])) &&
+                                (__double_as_longlong(lo[o].i) == __double_as_longlong(seen_i[o]));
+          if (periodic) {
+            skipped_steps += (unsigned long long) l_rem[o];
+            l_rem[o] = 0;
+            ended = true;
+          } else {
+            const int chunks_done = (long_steps - l_rem[o]) / kChunk;
+            if ((chunks_done & (chunks_done - 1)) == 0) {
+              seen_r[o] = lo[o].r;
+              seen_i[o] = lo[o].i;
+            }
+          }
+        }
+        const unsigned long long ended_mask = __ballot(ended);
+        if (ended_mask != 0ull) n_never += (unsigned long long) __popcll(ended_mask);
+      }
+      // leave the stage when another one has work to do
+      if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                       // REPLAY can fill every lane
+      if (q1_count < kQ1Low && (samples_left != 0 || q0_count > 0)) break;        // HEAD / MID must top up
+    }
+    if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
+  }
+
+  if (valid) store_rng(a.states, a.n_threads, tid, rng);
+  if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
+  const unsigned long long skipped_total = wave_sum(skipped_steps);
+  if (a.counters && lane_id() == 0) {
+    unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
+    const unsigned long long n_samples =
+        (unsigned long long) __popcll(valid_mask) * (unsigned long long) a.samples_per_thread;
+    const unsigned long long v[9] = {n_samples, n_rejected, n_never,  n_too_fast, n_recorded,
+                                     n_iterate + skipped_total, n_replay, n_incr, skipped_total};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (status) __hip_atomic_fetch_or(c + 9, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kTimed) {
+      const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_start;
+      __hip_atomic_fetch_add(c + 10, t_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 11, t_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 12, t_replay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 13, t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // wave residency on the 100 MHz constant clock: first start (kept as max of ~start), last end,
+      // and the sum of wave lifetimes
+      const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+      __hip_atomic_fetch_max(c + 14, ~rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(c + 15, rt_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 16, rt_end - rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.wave_dump) {
+        unsigned long long *d = a.wave_dump + (size_t) wave_id * 8;
+        d[0] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all bits
+        // XCC id (4 bits) | full LONG chunks run (28 bits) | orbit slots active in them (32 bits)
+        d[1] = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xfu) |
+               ((dbg_chunks & 0xfffffffull) << 4) | (dbg_slots << 32);
+        d[2] = rt_start;
+        d[3] = rt_end;
+        d[4] = t_head;
+        d[5] = t_long;
+        d[6] = t_replay;
+        d[7] = t_all;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
+  if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
+  const uint32_t threads = 64 * kWavesPerBlock;
+  const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
+  const bool binned = a.bin.enabled != 0u;
+  if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
+  if (timed && binned) {
+    hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else if (timed) {
+    hipLaunchKernelGGL((draw_wave_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else if (binned) {
+    hipLaunchKernelGGL((draw_wave_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL((draw_wave_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
+  }
+  return hipGetLastError();
+}
+
+// Stage split.  HEAD does iterations [0, head), MID [head, head + mid), LONG the rest in chunks of
+// kChunk.  mid is chosen so that min_iter - (head + mid) is a multiple of kChunk whenever min_iter
+// lies beyond the MID stage: then no LONG chunk straddles min_iter.
+void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps) {
+  const int kHead = 4, kMidMin = 12;
+  int head = kHead;
+  if (max_iter < head) head = max_iter < 0 ? 0 : max_iter;
+  int rem = max_iter - head;
+  int mid = 0;
+  if (rem > 0) {
+    if (min_iter <= head + kMidMin) {
+      mid = 16;
+    } else {
+      mid = kMidMin + ((min_iter - head - kMidMin) % kChunk);
+    }
+    if (mid > rem) mid = rem;  // shallow runs: HEAD + MID do all of it
+  }
+  *head_steps = head;
+  *mid_steps = mid;
+}
+
+}  // namespace cb

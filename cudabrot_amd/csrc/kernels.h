@@ -63,8 +63,9 @@ struct DrawArgs {
   int w, h, pow2_real, pow2_imag;
   // iteration control (cudabrot.cu:62-67)
   int max_iter, min_iter;
-  // stage split: samples enter the long-iterate stage after exactly head_steps iterations
-  int head_steps;
+  // stage split of draw_wave_kernel (plan_stages): HEAD runs iterations [0, head_steps), MID the
+  // next mid_steps, LONG the rest
+  int head_steps, mid_steps;
   uint32_t n_threads;
   uint32_t samples_per_thread;
   unsigned long long *hist;
@@ -89,9 +90,8 @@ hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n
 hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream);
 hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
 
-// Steps per chunk of the long-iterate stage; head_steps is chosen so that
-// (min_iter - head_steps) % kChunk == 0 whenever min_iter lies beyond the head.
-constexpr int kChunk = 16;
-int choose_head_steps(int max_iter, int min_iter);
+// Steps per chunk of the LONG stage; the stage split is chosen so that no chunk straddles min_iter.
+constexpr int kChunk = 32;
+void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps);
 
 }  // namespace cb

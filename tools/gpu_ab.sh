@@ -31,7 +31,9 @@ for line in sys.stdin:
 C3="-w 4096 -h 4096 -m 20000"
 C2="-w 4096 -h 4096 -m 2000"
 one c3_p64_timed CUDABROT_AMD_WAVE_DUMP=gpurun_out/wave_dump_c3.bin -- $C3 --passes 64 --kernel timed
+one c2_p64_timed CUDABROT_AMD_WAVE_DUMP=gpurun_out/wave_dump_c2.bin -- $C2 --passes 64 --kernel timed
 one c3_t5 X=1 -- $C3 -t 5
 one c2_t5 X=1 -- $C2 -t 5
 one def_t5 X=1 -- -t 5
+one c3_full_t5 X=1 -- $C3 -t 5 --kernel full
 echo AB DONE
