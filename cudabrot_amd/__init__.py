@@ -19,6 +19,7 @@ from .capi import (  # noqa: F401
     FractalDimensions,
     IterationControl,
     Renderer,
+    carry_bytes,
     draw_buddhabrot,
     flush_scatter,
     initialize_rng,
@@ -45,6 +46,7 @@ __all__ = [
     "FractalDimensions",
     "IterationControl",
     "Renderer",
+    "carry_bytes",
     "draw_buddhabrot",
     "flush_scatter",
     "initialize_rng",

@@ -141,7 +141,9 @@ def _load():
         "cb_rng_state_bytes": (C.c_size_t, [u32]),
         "cb_initialize_rng": (i32, [u64, u64, u32, vp, vp]),
         "cb_scatter_workspace_bytes": (C.c_size_t, [dims_p, u32, u32]),
-        "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp, C.c_size_t, vp]),
+        "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp, C.c_size_t, vp, vp]),
+        "cb_carry_bytes": (C.c_size_t, [u32]),
+        "cb_renderer_finish": (i32, [vp]),
         "cb_flush_scatter": (i32, [dims_p, vp, u32, vp, C.c_size_t, vp]),
         "cb_renderer_create": (i32, [C.POINTER(vp), i32, dims_p, it_p, u64, u64, u32]),
         "cb_renderer_render_passes": (i32, [vp, u32, i32]),
@@ -163,7 +165,8 @@ def _load():
 lib = _load()
 EXPORTED_SYMBOLS = (
     "cb_abi_version cb_error_string cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
-    "cb_scatter_workspace_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create cb_renderer_render_passes "
+    "cb_scatter_workspace_bytes cb_carry_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create "
+    "cb_renderer_render_passes cb_renderer_finish "
     "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image"
@@ -200,14 +203,21 @@ def scatter_workspace_bytes(dims, n_threads, samples_per_thread):
     return int(lib.cb_scatter_workspace_bytes(C.byref(dims), n_threads, samples_per_thread))
 
 
+def carry_bytes(n_threads):
+    """Size of the carry buffer (in-flight orbits handed from launch to launch)."""
+    return int(lib.cb_carry_bytes(n_threads))
+
+
 def draw_buddhabrot(dims, d_hist, iterations, d_states, n_threads, samples_per_thread, d_counters=0,
-                    kernel_variant=CB_KERNEL_DEFAULT, stream=0, d_workspace=0, workspace_bytes=0):
+                    kernel_variant=CB_KERNEL_DEFAULT, stream=0, d_workspace=0, workspace_bytes=0, d_carry=0):
     """DrawBuddhabrot (cudabrot.cu:379-414,485-486) on caller-owned device memory; asynchronous.
-    With a workspace the increments go through the deferred tile-binned scatter, else direct atomics."""
+    With a workspace the increments go through the deferred tile-binned scatter, else direct atomics.
+    With a (zeroed) carry buffer, orbits still in flight are handed to the next call; a last call with
+    samples_per_thread=0 completes them."""
     _check(
         lib.cb_draw_buddhabrot(C.byref(dims), d_hist, C.byref(iterations), d_states, n_threads,
                                samples_per_thread, d_counters, kernel_variant, d_workspace, workspace_bytes,
-                               stream),
+                               d_carry, stream),
         "cb_draw_buddhabrot",
     )
 
@@ -235,6 +245,10 @@ class Renderer:
 
     def render_passes(self, passes, kernel_variant=CB_KERNEL_DEFAULT):
         _check(lib.cb_renderer_render_passes(self._h, passes, kernel_variant), "cb_renderer_render_passes")
+
+    def finish(self):
+        """Complete the orbits carried between launches (the read functions do this themselves)."""
+        _check(lib.cb_renderer_finish(self._h), "cb_renderer_finish")
 
     def read_histogram(self):
         out = np.empty(self.dims.w * self.dims.h, dtype=np.uint64)

@@ -64,7 +64,7 @@ unsigned long long *g_wave_dump = nullptr;
 cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_control *it,
                        cb_pixel *d_hist, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, void *d_workspace,
-                       size_t workspace_bytes) {
+                       size_t workspace_bytes, void *d_carry) {
   cb::DrawArgs a;
   memset(&a, 0, sizeof(a));
   a.min_real = dims->min_real;
@@ -89,6 +89,8 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
                               cb::draw_wave_count(n_threads));
   a.wave_dump = g_wave_dump;
   a.check_periodic = 1;
+  a.carry = reinterpret_cast<unsigned long long *>(d_carry);
+  a.drain = (d_carry != nullptr && samples_per_thread == 0) ? 1 : 0;
   return a;
 }
 
@@ -117,7 +119,66 @@ struct cb_renderer {
   bool flush_pending[2];
   hipEvent_t draw_done[2], flush_done[2];
   hipStream_t stream, flush_stream;
+  // In-flight work carried from launch to launch (cb_draw_buddhabrot's d_carry); drained lazily by
+  // finish() before anything reads the histogram or the counters.
+  void *d_carry;
+  bool carry_pending;
+  int carry_variant;
 };
+
+namespace {
+
+// Adds one launch (or, with passes == 0, the drain of the carried work) and its flush to the
+// renderer's streams.
+int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
+  const bool wave = kernel_variant != CB_KERNEL_SIMPLE;
+  const bool deferred = r->d_workspace[0] && wave;
+  const int k = r->next_workspace;
+  if (deferred && r->flush_pending[k]) {
+    // workspace k is free again once the flush that read it has finished
+    CB_TRY(hipStreamWaitEvent(r->stream, r->flush_done[k], 0));
+    r->flush_pending[k] = false;
+  }
+  int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
+                              passes * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
+                              deferred ? r->d_workspace[k] : nullptr, r->workspace_bytes,
+                              wave ? r->d_carry : nullptr, r->stream);
+  if (rc) return rc;
+  if (wave && r->d_carry) {
+    r->carry_pending = passes != 0;
+    r->carry_variant = kernel_variant;
+  }
+  if (deferred) {
+    CB_TRY(hipEventRecord(r->draw_done[k], r->stream));
+    CB_TRY(hipStreamWaitEvent(r->flush_stream, r->draw_done[k], 0));
+    rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace[k], r->workspace_bytes,
+                          r->flush_stream);
+    if (rc) return rc;
+    CB_TRY(hipEventRecord(r->flush_done[k], r->flush_stream));
+    r->flush_pending[k] = true;
+    r->next_workspace = k ^ 1;
+  }
+  return 0;
+}
+
+int sync_streams(cb_renderer *r) {
+  CB_TRY(hipStreamSynchronize(r->stream));
+  CB_TRY(hipStreamSynchronize(r->flush_stream));
+  r->flush_pending[0] = r->flush_pending[1] = false;
+  return 0;
+}
+
+// Completes the work earlier launches left in the carry buffer: after this the histogram and the
+// counters account for every sample drawn so far.
+int finish(cb_renderer *r) {
+  if (r->carry_pending) {
+    int rc = enqueue_launch(r, 0, r->carry_variant);
+    if (rc) return rc;
+  }
+  return sync_streams(r);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -163,6 +224,10 @@ int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_thre
                                    reinterpret_cast<hipStream_t>(stream));
 }
 
+size_t cb_carry_bytes(uint32_t n_threads) {
+  return (size_t) cb::draw_wave_count(n_threads) * cb::kCarryWordsPerWave * sizeof(unsigned long long);
+}
+
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
                                   uint32_t samples_per_thread) {
   if (!dims || dims->w <= 0 || dims->h <= 0 || dims->w > 65536 || dims->h > 65536) return 0;
@@ -180,12 +245,15 @@ size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
-                       void *d_workspace, size_t workspace_bytes, void *stream) {
+                       void *d_workspace, size_t workspace_bytes, void *d_carry, void *stream) {
   if (!dims || !iterations || !d_hist || !d_states) return (int) hipErrorInvalidValue;
   if (dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
-  if (kernel_variant == CB_KERNEL_SIMPLE) d_workspace = nullptr;  // the baseline kernel always uses atomics
+  if (kernel_variant == CB_KERNEL_SIMPLE) {  // the baseline kernel: atomics, every launch complete
+    d_workspace = nullptr;
+    d_carry = nullptr;
+  }
   const cb::DrawArgs a = make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread,
-                                   d_counters, d_workspace, workspace_bytes);
+                                   d_counters, d_workspace, workspace_bytes, d_carry);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   switch (kernel_variant) {
     case CB_KERNEL_DEFAULT:
@@ -240,6 +308,8 @@ int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimension
   if (e == hipSuccess) e = hipMemsetAsync(r->d_hist, 0, hist_bytes, r->stream);  // cudabrot.cu:169
   if (e == hipSuccess) e = hipMalloc(&r->d_states, cb_rng_state_bytes(n_threads));  // :177
   if (e == hipSuccess) e = hipMalloc(&r->d_counters, sizeof(cb_counters));
+  if (e == hipSuccess) e = hipMalloc(&r->d_carry, cb_carry_bytes(n_threads));
+  if (e == hipSuccess) e = hipMemsetAsync(r->d_carry, 0, cb_carry_bytes(n_threads), r->stream);
   if (e == hipSuccess) e = hipMemsetAsync(r->d_counters, 0, sizeof(cb_counters), r->stream);
   int rc = (int) e;
   if (!rc) rc = cb_initialize_rng(seed, first_subsequence, n_threads, r->d_states, r->stream);
@@ -287,33 +357,22 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
       }
     }
   }
-  const bool deferred = r->d_workspace[0] && kernel_variant != CB_KERNEL_SIMPLE;
+  if (r->carry_pending && r->carry_variant != kernel_variant) {
+    int rc = finish(r);  // a different kernel variant cannot take over the carried work
+    if (rc) return rc;
+  }
   while (passes > 0) {
     const uint32_t now = passes < max_passes_per_launch ? passes : max_passes_per_launch;
-    const int k = r->next_workspace;
-    if (deferred && r->flush_pending[k]) {
-      // workspace k is free again once the flush that read it has finished
-      CB_TRY(hipStreamWaitEvent(r->stream, r->flush_done[k], 0));
-      r->flush_pending[k] = false;
-    }
-    int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
-                                now * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
-                                deferred ? r->d_workspace[k] : nullptr, r->workspace_bytes, r->stream);
+    int rc = enqueue_launch(r, now, kernel_variant);
     if (rc) return rc;
-    if (deferred) {
-      CB_TRY(hipEventRecord(r->draw_done[k], r->stream));
-      CB_TRY(hipStreamWaitEvent(r->flush_stream, r->draw_done[k], 0));
-      rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace[k], r->workspace_bytes,
-                            r->flush_stream);
-      if (rc) return rc;
-      CB_TRY(hipEventRecord(r->flush_done[k], r->flush_stream));
-      r->flush_pending[k] = true;
-      r->next_workspace = k ^ 1;
-    }
     passes -= now;
   }
-  CB_TRY(hipStreamSynchronize(r->flush_stream));  // the histogram is complete when this call returns
-  r->flush_pending[0] = r->flush_pending[1] = false;
+  // The launches are complete when this returns; the orbits still in flight are carried to the next
+  // call and finished before anything reads the histogram or the counters (finish()).
+  {
+    int rc = sync_streams(r);
+    if (rc) return rc;
+  }
   if (g_wave_dump) {  // diagnostic: write the per-wave records of the last launch
     (void) hipStreamSynchronize(r->stream);
     const size_t n = (size_t) cb::draw_wave_count(r->n_threads) * 8;
@@ -330,9 +389,19 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
   return (int) hipStreamSynchronize(r->stream);  // cudabrot.cu:487
 }
 
+int cb_renderer_finish(cb_renderer *r) {
+  if (!r) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  return finish(r);
+}
+
 int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out) {
   if (!r || !host_out) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);
+    if (rc) return rc;
+  }
   const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
   CB_TRY(hipMemcpyAsync(host_out, r->d_hist, bytes, hipMemcpyDeviceToHost, r->stream));
   return (int) hipStreamSynchronize(r->stream);
@@ -341,6 +410,10 @@ int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out) {
 int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in) {
   if (!r || !host_in) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);
+    if (rc) return rc;
+  }
   const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
   CB_TRY(hipMemcpyAsync(r->d_hist, host_in, bytes, hipMemcpyHostToDevice, r->stream));
   return (int) hipStreamSynchronize(r->stream);
@@ -349,6 +422,10 @@ int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in) {
 int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out) {
   if (!r || !host_out) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);
+    if (rc) return rc;
+  }
   CB_TRY(hipMemcpyAsync(host_out, r->d_counters, sizeof(cb_counters), hipMemcpyDeviceToHost,
                         r->stream));
   return (int) hipStreamSynchronize(r->stream);
@@ -364,6 +441,7 @@ void cb_renderer_destroy(cb_renderer *r) {
   (void) hipFree(r->d_hist);
   (void) hipFree(r->d_states);
   (void) hipFree(r->d_counters);
+  (void) hipFree(r->d_carry);
   (void) hipFree(r->d_workspace[0]);
   (void) hipFree(r->d_workspace[1]);
   for (int k = 0; k < 2; ++k) {

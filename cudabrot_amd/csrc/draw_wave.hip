@@ -47,7 +47,8 @@ constexpr int kOrbitsPerLane = 2;      // deep orbits a lane iterates side by si
 constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
 constexpr int kQ1Cap = 128;            // MID survivors: (c, z)        (4 KiB per wave)
 constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
-constexpr int kQ1Low = 16;             // run MID while fewer deep orbits than this are queued
+constexpr int kQ1Low = 48;             // run MID while fewer deep orbits than this are queued
+constexpr int kQ1Exit = 8;             // LONG hands over to HEAD / MID below this many
 constexpr int kReplayMin = 32;         // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = 8;   // replay steps per asm burst
 constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
@@ -404,8 +405,44 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
   bool p_act = false;
   int p_steps = 0;
 
+  // Carry-over: pick up the queues and orbit slots the previous launch left behind (DrawArgs::carry).
+  static_assert(sizeof(WaveQueues) == kCarryQueueWords * 8, "carry layout follows WaveQueues");
+  unsigned long long *const carry =
+      a.carry ? a.carry + (size_t) wave_id * kCarryWordsPerWave : nullptr;
+  if (carry && carry[0] == 1ull) {  // wave-uniform: the header is one address
+    q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
+    q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));
+    q1_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[2]);
+    q1_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[2] >> 32));
+    q2_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[3]);
+    q2_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[3] >> 32));
+    unsigned long long *lds_words = reinterpret_cast<unsigned long long *>(&q);
+    const unsigned long long *img = carry + kCarryHeaderWords;
+    for (uint32_t k = lane_id(); k < kCarryQueueWords; k += 64u) lds_words[k] = img[k];
+    const unsigned long long *pl = img + kCarryQueueWords + lane_id();
+#pragma unroll
+    for (int o = 0; o < kOrbitsPerLane; ++o) {
+      lo[o].cr = __longlong_as_double((long long) pl[(o * 4 + 0) * 64]);
+      lo[o].ci = __longlong_as_double((long long) pl[(o * 4 + 1) * 64]);
+      lo[o].r = __longlong_as_double((long long) pl[(o * 4 + 2) * 64]);
+      lo[o].i = __longlong_as_double((long long) pl[(o * 4 + 3) * 64]);
+      seen_r[o] = __longlong_as_double((long long) pl[(8 + o * 2 + 0) * 64]);
+      seen_i[o] = __longlong_as_double((long long) pl[(8 + o * 2 + 1) * 64]);
+    }
+    po.cr = __longlong_as_double((long long) pl[12 * 64]);
+    po.ci = __longlong_as_double((long long) pl[13 * 64]);
+    po.r = __longlong_as_double((long long) pl[14 * 64]);
+    po.i = __longlong_as_double((long long) pl[15 * 64]);
+    l_rem[0] = (int) (uint32_t) pl[16 * 64];
+    l_rem[1] = (int) (uint32_t) (pl[16 * 64] >> 32);
+    p_steps = (int) (uint32_t) pl[17 * 64];
+    p_act = (pl[17 * 64] >> 32) != 0ull;
+  }
+
   for (;;) {
     const bool input_done = (samples_left == 0);
+    // with a carry buffer the in-flight work is left for the next launch instead of being drained
+    if (input_done && carry && !a.drain) break;
     const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0) != 0ull;
     const bool draining = input_done && (q0_count == 0) && (q1_count == 0) && !l_any;
     const int n_replaying = __popcll(__ballot(p_act));
@@ -701,13 +738,40 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
       }
       // leave the stage when another one has work to do
       if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                       // REPLAY can fill every lane
-      if (q1_count < kQ1Low && (samples_left != 0 || q0_count > 0)) break;        // HEAD / MID must top up
+      if (q1_count < kQ1Exit && (samples_left != 0 || q0_count > 0)) break;       // HEAD / MID must top up
     }
     if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
   }
 
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
   if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
+  if (carry) {  // leave queues and orbit slots for the next launch (empty after a drain)
+    if (lane_id() == 0) {
+      carry[0] = 1ull;
+      carry[1] = (unsigned long long) (uint32_t) q0_head | ((unsigned long long) (uint32_t) q0_count << 32);
+      carry[2] = (unsigned long long) (uint32_t) q1_head | ((unsigned long long) (uint32_t) q1_count << 32);
+      carry[3] = (unsigned long long) (uint32_t) q2_head | ((unsigned long long) (uint32_t) q2_count << 32);
+    }
+    const unsigned long long *lds_words = reinterpret_cast<const unsigned long long *>(&q);
+    unsigned long long *img = carry + kCarryHeaderWords;
+    for (uint32_t k = lane_id(); k < kCarryQueueWords; k += 64u) img[k] = lds_words[k];
+    unsigned long long *pl = img + kCarryQueueWords + lane_id();
+#pragma unroll
+    for (int o = 0; o < kOrbitsPerLane; ++o) {
+      pl[(o * 4 + 0) * 64] = (unsigned long long) __double_as_longlong(lo[o].cr);
+      pl[(o * 4 + 1) * 64] = (unsigned long long) __double_as_longlong(lo[o].ci);
+      pl[(o * 4 + 2) * 64] = (unsigned long long) __double_as_longlong(lo[o].r);
+      pl[(o * 4 + 3) * 64] = (unsigned long long) __double_as_longlong(lo[o].i);
+      pl[(8 + o * 2 + 0) * 64] = (unsigned long long) __double_as_longlong(seen_r[o]);
+      pl[(8 + o * 2 + 1) * 64] = (unsigned long long) __double_as_longlong(seen_i[o]);
+    }
+    pl[12 * 64] = (unsigned long long) __double_as_longlong(po.cr);
+    pl[13 * 64] = (unsigned long long) __double_as_longlong(po.ci);
+    pl[14 * 64] = (unsigned long long) __double_as_longlong(po.r);
+    pl[15 * 64] = (unsigned long long) __double_as_longlong(po.i);
+    pl[16 * 64] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
+    pl[17 * 64] = (unsigned long long) (uint32_t) p_steps | ((unsigned long long) (p_act ? 1u : 0u) << 32);
+  }
   const unsigned long long skipped_total = wave_sum(skipped_steps);
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
@@ -752,7 +816,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
 }  // namespace
 
 hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
-  if (a.n_threads == 0 || a.samples_per_thread == 0) return hipSuccess;
+  const bool drain_launch = a.carry != nullptr && a.drain != 0;
+  if (a.n_threads == 0 || (a.samples_per_thread == 0 && !drain_launch)) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
   const bool binned = a.bin.enabled != 0u;

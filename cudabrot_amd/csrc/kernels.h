@@ -78,7 +78,19 @@ struct DrawArgs {
   // 1: retire orbits found exactly periodic (default); 0: iterate every sample to max_iter like the
   // reference does (CB_KERNEL_FULL_ITERATE, for measuring the iterate loop against its roofline)
   int check_periodic;
+  // Carry-over of in-flight work (may be null).  Draining a launch is expensive: the deepest orbits
+  // take hundreds of chunks with almost every lane idle.  With a carry buffer a launch stops when
+  // its samples are drawn and leaves queues and orbit slots in the buffer for the next launch; a
+  // launch with drain != 0 (and normally no samples) finishes everything.  kCarryWordsPerWave u64
+  // words per wave, zeroed by the caller before the first launch.
+  unsigned long long *carry;
+  int drain;
 };
+
+constexpr uint32_t kCarryHeaderWords = 8;
+constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 128 + 2 * 192);  // = sizeof(WaveQueues) / 8
+constexpr uint32_t kCarryLanePlanes = 18;
+constexpr uint32_t kCarryWordsPerWave = kCarryHeaderWords + kCarryQueueWords + kCarryLanePlanes * 64;
 
 constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup
 inline uint32_t draw_wave_count(uint32_t n_threads) {

@@ -116,11 +116,22 @@ size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_
  * With one, the increments that fit are DEFERRED: the kernel streams the visited pixels into the
  * workspace and the caller must then run cb_flush_scatter on the same workspace (stream-ordered
  * after this call) before it reads d_hist or reuses the workspace; what does not fit is added
- * atomically at once, so the sum is the same for any workspace size. */
+ * atomically at once, so the sum is the same for any workspace size.
+ * d_carry (may be NULL: then the launch completes every sample it draws, like the reference's) is
+ * cb_carry_bytes(n_threads) of device memory, zeroed before the first call, that carries orbits
+ * still in flight from one launch to the next: finishing the deepest orbits of a launch takes
+ * hundreds of iterations with almost every lane idle, so with a carry buffer the launch stops when
+ * its samples are drawn.  A final call with samples_per_thread == 0 (followed by its
+ * cb_flush_scatter) completes the carried work; only then do d_hist and d_counters account for
+ * every sample drawn.  Same geometry, iteration control and kernel variant for all calls sharing a
+ * carry buffer. */
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
-                       void *d_workspace, size_t workspace_bytes, void *stream);
+                       void *d_workspace, size_t workspace_bytes, void *d_carry, void *stream);
+
+/* Bytes of the carry buffer of cb_draw_buddhabrot for n_threads threads. */
+size_t cb_carry_bytes(uint32_t n_threads);
 
 /* Second half of the scatter: partitions the pixel stream a cb_draw_buddhabrot call left in
  * d_workspace by 128x128-pixel tile (counting sort) and adds every tile to d_hist from an LDS
@@ -139,8 +150,13 @@ int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimension
                        const cb_iteration_control *iterations, uint64_t seed,
                        uint64_t first_subsequence, uint32_t n_threads);
 /* `passes` iterations of the loop body of RenderImage (cudabrot.cu:483-487), fused into as few
- * launches as possible; returns after the device has finished them. */
+ * launches as possible; returns after the device has finished them.  Orbits still in flight are
+ * carried to the next call; cb_renderer_finish (called by the read/write functions below) completes
+ * them. */
 int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant);
+/* Completes all carried work: afterwards the device histogram and counters account for every sample
+ * of every pass rendered so far (needed before using cb_renderer_device_histogram directly). */
+int cb_renderer_finish(cb_renderer *r);
 /* The cudaMemcpy of cudabrot.cu:496-497: host_out receives w*h cb_pixel. */
 int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out);
 /* The H2D copy of LoadInProgressBuffer (cudabrot.cu:256-257): REPLACES the device histogram. */

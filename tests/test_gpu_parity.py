@@ -187,6 +187,51 @@ def test_periodicity_early_out_changes_nothing_but_the_work(cb, oracle):
     assert early[1]["skipped_steps"] > 0.5 * early[1]["iterate_steps"]   # deep orbits: most work is skipped
 
 
+@pytest.mark.parametrize("use_workspace", [True, False])
+def test_carry_buffer_hands_in_flight_orbits_to_the_next_launch(cb, oracle, use_workspace):
+    """With a carry buffer a launch stops when its samples are drawn; the orbits still in flight are
+    finished by later launches, the last one being a drain (samples_per_thread = 0).  Only then do the
+    histogram and the counters match the reference."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    w, h, t, launches = 384, 256, 4096, 5
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(5000, 20)
+    states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    carry = torch.zeros(cb.carry_bytes(t), dtype=torch.uint8, device=dev)
+    ws_bytes = cb.scatter_workspace_bytes(dims, t, 100) if use_workspace else 0
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
+
+    def launch(samples):
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), t, samples, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, ws.data_ptr() if ws_bytes else 0, ws_bytes, carry.data_ptr())
+        if ws_bytes:
+            cb.flush_scatter(dims, hist.data_ptr(), t, ws.data_ptr(), ws_bytes, stream)
+
+    for _ in range(launches):
+        launch(100)   # two reference passes per launch
+    torch.cuda.synchronize()
+    cpu, cc = oracle.render(w, h, 5000, 20, t, 2 * launches)
+    partial = hist.cpu().numpy().view(np.uint64).reshape(h, w)
+    c = counters.cpu().numpy().view(np.uint64)
+    assert int(c[0]) == cc["samples"]                              # every sample has been drawn ...
+    assert int(partial.sum()) < int(cpu.sum())                     # ... but some orbits are still in flight
+    assert np.all(partial <= cpu)
+    launch(0)         # drain
+    torch.cuda.synchronize()
+    got = hist.cpu().numpy().view(np.uint64).reshape(h, w)
+    cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
+    assert_same((got, cnt), (cpu, cc))
+    launch(0)         # a second drain finds nothing left
+    torch.cuda.synchronize()
+    assert np.array_equal(hist.cpu().numpy().view(np.uint64).reshape(h, w), cpu)
+
+
 def _torch_render(cb, w, h, max_iter, min_iter, t, passes, workspace_bytes, box=BOX):
     import torch
 
