@@ -39,7 +39,10 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
                     pmc[k]["_dispatch"] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                                              "VGPR_Count", "SGPR_Count")}
         for (k, c), v in agg.items():
-            pmc[k][c] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v), "pass": os.path.basename(d)}
+            # the MEDIAN dispatch: a bench run also issues drain launches (no samples, little traffic)
+            med = sorted(v)[len(v) // 2]
+            pmc[k][c] = {"mean_per_dispatch": med, "statistic": "median over dispatches", "all": v,
+                         "dispatches": len(v), "pass": os.path.basename(d)}
 
 
 def traffic(kernels):
@@ -49,6 +52,14 @@ def traffic(kernels):
     write = sum(pmc[k].get("WRITE_SIZE", {}).get("mean_per_dispatch", 0.0) for k in kernels) * 1024
     return {"fetch_bytes_corrected": fetch, "write_bytes": write, "total": fetch + write}
 
+
+# per-dispatch durations of the draw kernel from the kernel trace (the timed steps, the warm-up and the
+# drain launches of one bench run)
+durations = []
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    for r in csv.DictReader(open(f)):
+        if "draw_wave_kernel" in r["Kernel_Name"]:
+            durations.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4))
 
 bench = None
 bf = os.path.join(src, "bench_full.json")
@@ -67,6 +78,7 @@ out = {
                                     "bin_scatter_kernel", "bin_accumulate_kernel"]),
         "note": "per launch of 64 fused passes; fabric-side (TCC_EA) bytes, Infinity-Cache hits included",
     },
+    "draw_wave_kernel_dispatch_ms": durations,
     "bench_line": bench,
 }
 json.dump(out, open(dst + "_summary.json", "w"), indent=1)
