@@ -79,7 +79,7 @@ typedef struct {
 #define CB_STATUS_REPLAY_RUNAWAY 2u
 
 /* Kernel variants of cb_draw_buddhabrot. */
-#define CB_KERNEL_DEFAULT 0 /* wave-scheduled three-stage kernel (the product path)               */
+#define CB_KERNEL_DEFAULT 0 /* wave-scheduled four-stage kernel (the product path)                */
 #define CB_KERNEL_SIMPLE 1  /* one lane = one reference thread, lock-step; a validation baseline  */
 #define CB_KERNEL_TIMED 2   /* the default kernel with per-stage s_memtime stamps (diagnostic build) */
 #define CB_KERNEL_FULL_ITERATE 3 /* the default kernel without the exact-periodicity early-out: every
