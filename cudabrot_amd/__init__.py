@@ -14,6 +14,9 @@ from .capi import (  # noqa: F401
     CB_KERNEL_SIMPLE,
     CB_KERNEL_TIMED,
     CB_SAMPLES_PER_THREAD,
+    CB_TONE_AUTO,
+    CB_TONE_LUT,
+    CB_TONE_THRESHOLDS,
     Counters,
     CudabrotError,
     FractalDimensions,
@@ -30,6 +33,8 @@ from .capi import (  # noqa: F401
     save_image,
     scatter_workspace_bytes,
     set_grayscale_pixels,
+    tone_map_device,
+    tone_value,
 )
 from .sharding import shard_subsequences  # noqa: F401
 
@@ -41,6 +46,9 @@ __all__ = [
     "CB_KERNEL_SIMPLE",
     "CB_KERNEL_TIMED",
     "CB_SAMPLES_PER_THREAD",
+    "CB_TONE_AUTO",
+    "CB_TONE_LUT",
+    "CB_TONE_THRESHOLDS",
     "Counters",
     "CudabrotError",
     "FractalDimensions",
@@ -58,4 +66,6 @@ __all__ = [
     "scatter_workspace_bytes",
     "set_grayscale_pixels",
     "shard_subsequences",
+    "tone_map_device",
+    "tone_value",
 ]

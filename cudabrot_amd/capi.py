@@ -21,6 +21,7 @@ CB_KERNEL_DEFAULT = 0
 CB_KERNEL_SIMPLE = 1
 CB_KERNEL_TIMED = 2
 CB_KERNEL_FULL_ITERATE = 3
+CB_TONE_AUTO, CB_TONE_LUT, CB_TONE_THRESHOLDS = 0, 1, 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -154,6 +155,10 @@ def _load():
         "cb_renderer_destroy": (None, [vp]),
         "cb_set_grayscale_pixels": (None, [vp, i32, i32, C.c_double, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cb_save_image": (i32, [C.c_char_p, vp, i32, i32]),
+        "cb_save_image_be": (i32, [C.c_char_p, vp, i32, i32]),
+        "cb_tone_value": (C.c_uint16, [u64, u64, C.c_double]),
+        "cb_tone_map_device": (i32, [vp, i32, i32, C.c_double, i32, vp, C.POINTER(u64), C.POINTER(C.c_double), vp]),
+        "cb_renderer_grayscale_image": (i32, [vp, C.c_double, i32, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib_, name)  # AttributeError here = the library does not export the ABI
@@ -169,7 +174,8 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_render_passes cb_renderer_finish "
     "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
-    "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image"
+    "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
+    "cb_tone_map_device cb_renderer_grayscale_image"
 ).split()
 
 
@@ -255,6 +261,17 @@ class Renderer:
         _check(lib.cb_renderer_read_histogram(self._h, out.ctypes.data), "cb_renderer_read_histogram")
         return out.reshape(self.dims.h, self.dims.w)
 
+    def grayscale_image(self, gamma, mode=0):
+        """Device tone map (N1) -> (big-endian u16 image [h,w] = the PGM body, max count, scale)."""
+        gray = np.empty((self.dims.h, self.dims.w), dtype=">u2")
+        mx, scale = C.c_uint64(), C.c_double()
+        _check(
+            lib.cb_renderer_grayscale_image(self._h, float(gamma), int(mode), gray.ctypes.data, C.byref(mx),
+                                            C.byref(scale)),
+            "cb_renderer_grayscale_image",
+        )
+        return gray, int(mx.value), float(scale.value)
+
     def write_histogram(self, hist):
         a = np.ascontiguousarray(hist, dtype=np.uint64).reshape(-1)
         if a.size != self.dims.w * self.dims.h:
@@ -296,6 +313,21 @@ def set_grayscale_pixels(hist, gamma):
     mx, scale = C.c_uint64(), C.c_double()
     lib.cb_set_grayscale_pixels(a.ctypes.data, w, h, float(gamma), gray.ctypes.data, C.byref(mx), C.byref(scale))
     return gray, int(mx.value), float(scale.value)
+
+
+def tone_value(count, max_count, gamma):
+    """One pixel of SetGrayscalePixels (cudabrot.cu:443-449,462-466)."""
+    return int(lib.cb_tone_value(int(count), int(max_count), float(gamma)))
+
+
+def tone_map_device(d_hist, w, h, gamma, d_gray_be, mode=0, stream=0):
+    """cb_tone_map_device on caller-owned device memory (integer pointers) -> (max count, scale)."""
+    mx, scale = C.c_uint64(), C.c_double()
+    _check(
+        lib.cb_tone_map_device(d_hist, w, h, float(gamma), int(mode), d_gray_be, C.byref(mx), C.byref(scale), stream),
+        "cb_tone_map_device",
+    )
+    return int(mx.value), float(scale.value)
 
 
 def save_image(path, gray):

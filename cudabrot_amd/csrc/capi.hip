@@ -407,6 +407,25 @@ int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out) {
   return (int) hipStreamSynchronize(r->stream);
 }
 
+int cb_renderer_grayscale_image(cb_renderer *r, double gamma, int mode, uint16_t *host_gray_be,
+                                uint64_t *max_out, double *scale_out) {
+  if (!r || !host_gray_be) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);
+    if (rc) return rc;
+  }
+  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(uint16_t);
+  uint16_t *d_gray = nullptr;
+  CB_TRY(hipMalloc(reinterpret_cast<void **>(&d_gray), bytes));
+  int rc = cb_tone_map_device(r->d_hist, r->dims.w, r->dims.h, gamma, mode, d_gray, max_out, scale_out,
+                              r->stream);
+  if (rc == 0) rc = (int) hipMemcpyAsync(host_gray_be, d_gray, bytes, hipMemcpyDeviceToHost, r->stream);
+  if (rc == 0) rc = (int) hipStreamSynchronize(r->stream);
+  (void) hipFree(d_gray);
+  return rc;
+}
+
 int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in) {
   if (!r || !host_in) return (int) hipErrorInvalidValue;
   CB_TRY(hipSetDevice(r->device));

@@ -42,6 +42,8 @@ struct Settings {
   long fixed_passes = -1;                           // --passes (extension; <0: run by the clock)
   int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
   bool print_stats = false;                         // --stats  (extension)
+  int tone_mode = CB_TONE_AUTO;                     // --tonemap (extension): device table / thresholds
+  bool host_tonemap = false;                        //   ... or the reference's host loop
 };
 
 // The usage text is the command's documented interface (cudabrot.cu:579-620) and is printed as is.
@@ -151,6 +153,13 @@ const std::vector<Flag> &flag_table() {
        }},
       {"--stats", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.print_stats = true; }},
+      {"--tonemap", Value::kText, nullptr, false,
+       [](Settings &s, long, double, const char *t) {
+         s.host_tonemap = strcmp(t, "host") == 0;
+         s.tone_mode = (strcmp(t, "lut") == 0)          ? CB_TONE_LUT
+                       : (strcmp(t, "thresholds") == 0) ? CB_TONE_THRESHOLDS
+                                                        : CB_TONE_AUTO;
+       }},
   };
   return table;
 }
@@ -250,8 +259,11 @@ class Run {
  private:
   Settings cfg_;
   cb_renderer *renderer_ = nullptr;
-  cb_pixel *counts_ = nullptr;   // host mirror of the histogram
+  cb_pixel *counts_ = nullptr;   // host mirror of the histogram (only with -s or --tonemap host)
   uint16_t *gray_ = nullptr;
+  bool gray_is_big_endian_ = false;
+
+  bool need_host_counts() const { return cfg_.inprogress_file != nullptr || cfg_.host_tonemap; }
 
   uint64_t pixel_count() const { return (uint64_t) cfg_.canvas.w * (uint64_t) cfg_.canvas.h; }
   uint64_t buffer_bytes() const { return pixel_count() * sizeof(cb_pixel); }
@@ -287,8 +299,10 @@ class Run {
     printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
     CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
                                 CB_DEFAULT_RNG_SEED, 0, CB_DEFAULT_THREADS));
-    counts_ = (cb_pixel *) calloc(1, buffer_bytes());
-    if (!counts_) die();
+    if (need_host_counts()) {
+      counts_ = (cb_pixel *) calloc(1, buffer_bytes());
+      if (!counts_) die();
+    }
     gray_ = (uint16_t *) calloc(pixel_count(), sizeof(uint16_t));
     if (!gray_) {
       printf("Failed allocating grayscale image.\n");
@@ -401,13 +415,23 @@ class Run {
       if (next > 4096) next = 4096;
       if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
     }
-    CB_CHECK(cb_renderer_read_histogram(renderer_, counts_));
+    if (need_host_counts()) {
+      CB_CHECK(cb_renderer_read_histogram(renderer_, counts_));  // cudabrot.cu:496-497
+    } else {
+      CB_CHECK(cb_renderer_finish(renderer_));
+    }
     printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
     if (cfg_.print_stats) print_stats();
     uint64_t max = 0;
     double scale = 0.0;
-    cb_set_grayscale_pixels(counts_, cfg_.canvas.w, cfg_.canvas.h, cfg_.gamma_correction, gray_,
-                            &max, &scale);
+    if (cfg_.host_tonemap) {
+      cb_set_grayscale_pixels(counts_, cfg_.canvas.w, cfg_.canvas.h, cfg_.gamma_correction, gray_,
+                              &max, &scale);
+    } else {  // tone map on the device: only the 16-bit image crosses to the host
+      CB_CHECK(cb_renderer_grayscale_image(renderer_, cfg_.gamma_correction, cfg_.tone_mode, gray_,
+                                           &max, &scale));
+      gray_is_big_endian_ = true;
+    }
     printf("Max value: %lu, scale: %f\n", (unsigned long) max, scale);  // cudabrot.cu:437
   }
 
@@ -435,7 +459,9 @@ class Run {
   void save_image() {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0
     static const char *const kWhy[] = {nullptr, "Failed opening output image.",
                                        "Failed writing pgm header.", "Failed writing pixel data."};
-    const int rc = cb_save_image(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h);
+    const int rc = gray_is_big_endian_
+                       ? cb_save_image_be(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h)
+                       : cb_save_image(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h);
     if (rc >= 1 && rc <= 3) printf("%s\n", kWhy[rc]);
   }
 #undef CB_CHECK

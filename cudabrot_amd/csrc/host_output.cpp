@@ -28,6 +28,18 @@ inline uint16_t to_u16(double v) {
 
 extern "C" {
 
+// The value of one pixel: GetLinearColorScale's scale, DoGammaCorrection (or the plain scaling of
+// cudabrot.cu:462-466 when gamma <= 0), the conversion to uint16.  ONE definition, used by the host
+// path below and by the tables of the device path (tonemap.hip), so that both give the same bytes.
+uint16_t cb_tone_value(uint64_t count, uint64_t max, double gamma) {
+  const double linear_scale = ((double) 0xffff) / ((double) max);  // cudabrot.cu:436
+  const double scaled = ((double) count) * linear_scale;
+  if (gamma <= 0.0) return to_u16(scaled);
+  const double top = 0xffff;
+  const double v = top * pow(scaled / top, 1 / gamma);  // cudabrot.cu:443-449
+  return (v != v) ? (uint16_t) 0 : clamp_u16(v);
+}
+
 void cb_set_grayscale_pixels(const cb_pixel *hist, int w, int h, double gamma, uint16_t *gray_out,
                              uint64_t *max_out, double *scale_out) {
   const uint64_t n = (uint64_t) w * (uint64_t) h;
@@ -36,24 +48,22 @@ void cb_set_grayscale_pixels(const cb_pixel *hist, int w, int h, double gamma, u
   for (uint64_t i = 0; i < n; i++) {
     if (hist[i] > max) max = hist[i];
   }
-  const double linear_scale = ((double) 0xffff) / ((double) max);
   if (max_out) *max_out = max;
-  if (scale_out) *scale_out = linear_scale;
-  // DoGammaCorrection, cudabrot.cu:443-449
-  const double top = 0xffff;
-  if (gamma <= 0.0) {
-    for (uint64_t i = 0; i < n; i++) gray_out[i] = to_u16(((double) hist[i]) * linear_scale);
-  } else {
-    const double exponent = 1 / gamma;
-    for (uint64_t i = 0; i < n; i++) {
-      const double scaled = ((double) hist[i]) * linear_scale;
-      const double v = top * pow(scaled / top, exponent);
-      gray_out[i] = (v != v) ? (uint16_t) 0 : clamp_u16(v);
-    }
-  }
+  if (scale_out) *scale_out = ((double) 0xffff) / ((double) max);
+  for (uint64_t i = 0; i < n; i++) gray_out[i] = cb_tone_value(hist[i], max, gamma);
 }
 
 int cb_save_image(const char *path, uint16_t *gray, int w, int h) {
+  const uint64_t pixel_count = (uint64_t) w * (uint64_t) h;
+  // big-endian samples, cudabrot.cu:566-570
+  for (uint64_t i = 0; i < pixel_count; i++) {
+    const uint16_t tmp = gray[i];
+    gray[i] = (uint16_t) (((tmp & 0xff) << 8) | (tmp >> 8));
+  }
+  return cb_save_image_be(path, gray, w, h);
+}
+
+int cb_save_image_be(const char *path, const uint16_t *gray_be, int w, int h) {
   const uint64_t pixel_count = (uint64_t) w * (uint64_t) h;
   FILE *output = fopen(path, "wb");
   if (!output) return 1;
@@ -61,12 +71,7 @@ int cb_save_image(const char *path, uint16_t *gray, int w, int h) {
     fclose(output);
     return 2;
   }
-  // big-endian samples, cudabrot.cu:566-570
-  for (uint64_t i = 0; i < pixel_count; i++) {
-    const uint16_t tmp = gray[i];
-    gray[i] = (uint16_t) (((tmp & 0xff) << 8) | (tmp >> 8));
-  }
-  if (!fwrite(gray, pixel_count * sizeof(uint16_t), 1, output)) {
+  if (!fwrite(gray_be, pixel_count * sizeof(uint16_t), 1, output)) {
     fclose(output);
     return 3;
   }

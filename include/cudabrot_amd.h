@@ -177,6 +177,29 @@ void cb_set_grayscale_pixels(const cb_pixel *hist, int w, int h, double gamma, u
  * or 1/2/3 = open / header / pixel-data failure (the reference prints and carries on). */
 int cb_save_image(const char *path, uint16_t *gray, int w, int h);
 
+/* The value of one pixel under SetGrayscalePixels: count scaled by 65535/max, gamma-corrected
+ * (cudabrot.cu:443-449) or plainly scaled when gamma <= 0 (cudabrot.cu:462-466), as uint16. */
+uint16_t cb_tone_value(uint64_t count, uint64_t max, double gamma);
+/* SaveImage for pixels that are already big-endian (the output of the device tone map). */
+int cb_save_image_be(const char *path, const uint16_t *gray_be, int w, int h);
+
+/* ---- Output stage on the device ---------------------------------------------- */
+
+#define CB_TONE_AUTO 0        /* table when max < 2^24, thresholds above */
+#define CB_TONE_LUT 1         /* host-evaluated table over every count in [0, max] */
+#define CB_TONE_THRESHOLDS 2  /* host-evaluated smallest count per output value + binary search */
+
+/* SetGrayscalePixels (cudabrot.cu:425-468) + the byte swap of SaveImage (cudabrot.cu:566-570) on a
+ * DEVICE histogram: d_gray_be receives w*h big-endian uint16 (the PGM body).  The map itself is
+ * evaluated by the host (cb_tone_value) into a table the device looks up, so the bytes equal
+ * cb_set_grayscale_pixels + cb_save_image's.  Synchronises `stream`. */
+int cb_tone_map_device(const cb_pixel *d_hist, int w, int h, double gamma, int mode,
+                       uint16_t *d_gray_be, uint64_t *max_out, double *scale_out, void *stream);
+/* The same for a renderer's histogram (finishes carried work first); host_gray_be receives the
+ * w*h big-endian pixels: 2 bytes per pixel cross PCIe instead of 8. */
+int cb_renderer_grayscale_image(cb_renderer *r, double gamma, int mode, uint16_t *host_gray_be,
+                                uint64_t *max_out, double *scale_out);
+
 const char *cb_error_string(int code);
 int cb_abi_version(void);
 

@@ -75,6 +75,24 @@ def test_set_grayscale_pixels_matches_oracle(cb, oracle, gamma):
     assert g1.max() == 65535 or gamma <= 0
 
 
+def test_tone_value_is_the_per_pixel_map_of_set_grayscale_pixels(cb, oracle):
+    """cb_tone_value feeds the device tone map's tables: it must be SetGrayscalePixels for one pixel."""
+    counts = np.array([[0, 1, 2, 3, 10, 999, 1000, 65535, 65536, 10**6 - 1, 10**6]], dtype=np.uint64)
+    for gamma in (1.0, 2.2, 0.45, 0.0, -3.0):
+        ref = oracle.set_grayscale_pixels(counts, gamma)[0].reshape(-1)
+        got = [cb.tone_value(int(c), 10**6, gamma) for c in counts.reshape(-1)]
+        assert got == ref.tolist()
+    assert cb.tone_value(0, 0, 1.0) == 0  # scale = inf, 0 * inf = NaN -> 0
+
+
+def test_save_image_be_writes_swapped_pixels_unchanged(cb, oracle, tmp_path):
+    gray = (np.arange(23 * 7, dtype=np.uint32) * 2777 % 65536).astype(np.uint16).reshape(7, 23)
+    path = str(tmp_path / "be.pgm")
+    be = np.ascontiguousarray(gray.astype(">u2"))
+    assert cb.lib.cb_save_image_be(path.encode(), be.ctypes.data, 23, 7) == 0
+    assert open(path, "rb").read() == oracle.encode_pgm(gray)
+
+
 def test_set_grayscale_pixels_empty_histogram(cb, oracle):
     """max == 0 -> scale = inf (cudabrot.cu:436); every pixel comes out 0."""
     z = np.zeros((8, 8), dtype=np.uint64)

@@ -101,6 +101,18 @@ def test_gamma_variants(exe, oracle, small_render, tmp_path, gamma):
         assert f.read() == oracle.encode_pgm(gray)
 
 
+@pytest.mark.parametrize("tonemap", ["host", "lut", "thresholds"])
+def test_tonemap_paths_write_the_same_image(exe, oracle, small_render, tmp_path, tonemap):
+    """--tonemap (extension): the device table forms and the reference's host loop give the same bytes."""
+    out = str(tmp_path / "t.pgm")
+    r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-g", "2.2", "--tonemap", tonemap, "-o", out)
+    assert r.returncode == 0
+    gray, mx, scale = oracle.set_grayscale_pixels(small_render[0], 2.2)
+    assert "Max value: %d, scale: %f" % (mx, scale) in r.stdout
+    with open(out, "rb") as f:
+        assert f.read() == oracle.encode_pgm(gray)
+
+
 def test_timed_run_renders_at_least_one_pass_and_stops(exe, tmp_path):
     out = str(tmp_path / "t.pgm")
     t0 = time.time()
