@@ -151,6 +151,8 @@ def _load():
         "cb_renderer_read_histogram": (i32, [vp, vp]),
         "cb_renderer_write_histogram": (i32, [vp, vp]),
         "cb_renderer_read_counters": (i32, [vp, cnt_p]),
+        "cb_renderer_read_rng_states": (i32, [vp, vp]),
+        "cb_renderer_write_rng_states": (i32, [vp, vp]),
         "cb_renderer_device_histogram": (vp, [vp]),
         "cb_renderer_destroy": (None, [vp]),
         "cb_set_grayscale_pixels": (None, [vp, i32, i32, C.c_double, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
@@ -175,7 +177,7 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
-    "cb_tone_map_device cb_renderer_grayscale_image"
+    "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states"
 ).split()
 
 
@@ -260,6 +262,18 @@ class Renderer:
         out = np.empty(self.dims.w * self.dims.h, dtype=np.uint64)
         _check(lib.cb_renderer_read_histogram(self._h, out.ctypes.data), "cb_renderer_read_histogram")
         return out.reshape(self.dims.h, self.dims.w)
+
+    def read_rng_states(self):
+        """True-resume checkpoint (N3): the generator states as bytes (six u32 planes of n_threads)."""
+        out = np.empty(rng_state_bytes(self.n_threads), dtype=np.uint8)
+        _check(lib.cb_renderer_read_rng_states(self._h, out.ctypes.data), "cb_renderer_read_rng_states")
+        return out
+
+    def write_rng_states(self, blob):
+        a = np.ascontiguousarray(blob, dtype=np.uint8).reshape(-1)
+        if a.size != rng_state_bytes(self.n_threads):
+            raise ValueError("generator state blob does not match n_threads")
+        _check(lib.cb_renderer_write_rng_states(self._h, a.ctypes.data), "cb_renderer_write_rng_states")
 
     def grayscale_image(self, gamma, mode=0):
         """Device tone map (N1) -> (big-endian u16 image [h,w] = the PGM body, max count, scale)."""

@@ -450,6 +450,30 @@ int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out) {
   return (int) hipStreamSynchronize(r->stream);
 }
 
+int cb_renderer_read_rng_states(cb_renderer *r, void *host_out) {
+  if (!r || !host_out) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);  // afterwards no orbit is in flight: states + histogram are a complete checkpoint
+    if (rc) return rc;
+  }
+  CB_TRY(hipMemcpyAsync(host_out, r->d_states, cb_rng_state_bytes(r->n_threads), hipMemcpyDeviceToHost,
+                        r->stream));
+  return (int) hipStreamSynchronize(r->stream);
+}
+
+int cb_renderer_write_rng_states(cb_renderer *r, const void *host_in) {
+  if (!r || !host_in) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  {
+    int rc = finish(r);
+    if (rc) return rc;
+  }
+  CB_TRY(hipMemcpyAsync(r->d_states, host_in, cb_rng_state_bytes(r->n_threads), hipMemcpyHostToDevice,
+                        r->stream));
+  return (int) hipStreamSynchronize(r->stream);
+}
+
 cb_pixel *cb_renderer_device_histogram(cb_renderer *r) { return r ? r->d_hist : nullptr; }
 
 void cb_renderer_destroy(cb_renderer *r) {

@@ -42,6 +42,8 @@ struct Settings {
   long fixed_passes = -1;                           // --passes (extension; <0: run by the clock)
   int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
   bool print_stats = false;                         // --stats  (extension)
+  uint64_t seed = CB_DEFAULT_RNG_SEED;              // --seed (extension; cudabrot.cu:37)
+  const char *rng_state_file = nullptr;             // --rng-state (extension): true-resume sidecar
   int tone_mode = CB_TONE_AUTO;                     // --tonemap (extension): device table / thresholds
   bool host_tonemap = false;                        //   ... or the reference's host loop
 };
@@ -153,6 +155,10 @@ const std::vector<Flag> &flag_table() {
        }},
       {"--stats", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.print_stats = true; }},
+      {"--seed", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) { s.seed = (uint64_t) i; }},
+      {"--rng-state", Value::kText, nullptr, false,
+       [](Settings &s, long, double, const char *t) { s.rng_state_file = t; }},
       {"--tonemap", Value::kText, nullptr, false,
        [](Settings &s, long, double, const char *t) {
          s.host_tonemap = strcmp(t, "host") == 0;
@@ -247,8 +253,10 @@ class Run {
     printf("Calculating image...\n");
     setup();
     load_inprogress();
+    load_rng_state();
     render();
     save_inprogress();
+    save_rng_state();
     printf("Saving image.\n");
     save_image();
     printf("Done! Output image saved: %s\n", cfg_.output_image);
@@ -298,7 +306,7 @@ class Run {
     cpu_mib /= (1024.0 * 1024.0);
     printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
     CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
-                                CB_DEFAULT_RNG_SEED, 0, CB_DEFAULT_THREADS));
+                                cfg_.seed, 0, CB_DEFAULT_THREADS));
     if (need_host_counts()) {
       counts_ = (cb_pixel *) calloc(1, buffer_bytes());
       if (!counts_) die();
@@ -378,6 +386,75 @@ class Run {
     fclose(f);
   }
 
+  // True-resume sidecar (extension, off unless --rng-state is given).  The -s buffer
+  // is the histogram only, so the reference -- and this program by default -- replays seed 1337 from
+  // the start when it resumes (cudabrot.cu:179,215-258).  The sidecar keeps the generator states, so
+  // that buffer + sidecar continue the sample stream: P1 passes, save, resume, P2 passes gives the
+  // histogram of one run of P1 + P2 passes.
+  struct RngStateHeader {
+    char magic[8];  // "CBRNGST1"
+    uint64_t seed, first_subsequence, passes_done;
+    uint32_t n_threads, reserved;
+  };
+  uint64_t passes_before_ = 0, passes_this_run_ = 0;
+
+  void load_rng_state() {
+    const char *path = cfg_.rng_state_file;
+    if (!path) return;
+    FILE *f = fopen(path, "rb");
+    printf("Loading generator state from %s.\n", path);
+    if (!f) {
+      if (errno == ENOENT) {
+        printf("File %s doesn't exist yet. Not loading.\n", path);
+        return;
+      }
+      printf("Failed opening %s: %s\n", path, strerror(errno));
+      die();
+    }
+    const size_t bytes = cb_rng_state_bytes(CB_DEFAULT_THREADS);
+    RngStateHeader hd;
+    std::vector<unsigned char> blob(bytes + 1);
+    const bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && memcmp(hd.magic, "CBRNGST1", 8) == 0 &&
+                    hd.seed == cfg_.seed && hd.first_subsequence == 0 &&
+                    hd.n_threads == CB_DEFAULT_THREADS &&
+                    fread(blob.data(), 1, bytes + 1, f) == bytes;  // exactly `bytes` left
+    fclose(f);
+    if (!ok) {
+      printf("%s is not a generator state for seed %lu and %u threads.\n", path,
+             (unsigned long) cfg_.seed, (unsigned) CB_DEFAULT_THREADS);
+      die();
+    }
+    passes_before_ = hd.passes_done;
+    printf("Continuing the sample stream after %lu passes.\n", (unsigned long) passes_before_);
+    CB_CHECK(cb_renderer_write_rng_states(renderer_, blob.data()));
+  }
+
+  void save_rng_state() {
+    const char *path = cfg_.rng_state_file;
+    if (!path) return;
+    printf("Saving generator state to %s.\n", path);
+    const size_t bytes = cb_rng_state_bytes(CB_DEFAULT_THREADS);
+    std::vector<unsigned char> blob(bytes);
+    CB_CHECK(cb_renderer_read_rng_states(renderer_, blob.data()));
+    RngStateHeader hd;
+    memset(&hd, 0, sizeof(hd));
+    memcpy(hd.magic, "CBRNGST1", 8);
+    hd.seed = cfg_.seed;
+    hd.passes_done = passes_before_ + passes_this_run_;
+    hd.n_threads = CB_DEFAULT_THREADS;
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+      printf("Failed opening %s: %s\n", path, strerror(errno));
+      die();
+    }
+    if (fwrite(&hd, sizeof(hd), 1, f) != 1 || fwrite(blob.data(), bytes, 1, f) != 1) {
+      printf("Failed writing data to %s: %s\n", path, strerror(errno));
+      fclose(f);
+      die();
+    }
+    fclose(f);
+  }
+
   // The pass loop (cudabrot.cu:471-501).  Launch length follows the measured pass time so that the
   // clock and the quit flag are looked at about every 0.2 s.
   void render() {
@@ -420,6 +497,7 @@ class Run {
     } else {
       CB_CHECK(cb_renderer_finish(renderer_));
     }
+    passes_this_run_ = (uint64_t) done;
     printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
     if (cfg_.print_stats) print_stats();
     uint64_t max = 0;

@@ -162,6 +162,12 @@ int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out);
 /* The H2D copy of LoadInProgressBuffer (cudabrot.cu:256-257): REPLACES the device histogram. */
 int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in);
 int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out);
+/* True-resume checkpoint: the generator states as an opaque blob of
+ * cb_rng_state_bytes(n_threads) bytes.  The reference's -s buffer holds the histogram only, so a
+ * resumed run replays seed 1337 from the start (cudabrot.cu:215-258,179); histogram + these states
+ * continue the sample stream instead.  Both finish carried work first. */
+int cb_renderer_read_rng_states(cb_renderer *r, void *host_out);
+int cb_renderer_write_rng_states(cb_renderer *r, const void *host_in);
 /* Device pointer of the histogram, for a caller-side RCCL reduce. */
 cb_pixel *cb_renderer_device_histogram(cb_renderer *r);
 /* CleanupGlobals (cudabrot.cu:112-119). */

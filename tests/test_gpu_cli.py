@@ -71,6 +71,34 @@ def test_resume_adds_to_the_saved_buffer(exe, small_render, tmp_path):
     assert np.array_equal(state, 2 * small_render[0])
 
 
+def test_rng_state_sidecar_continues_the_sample_stream(exe, oracle, tmp_path):
+    """--rng-state (extension): buffer + sidecar resume with NEW samples, so 2 passes,
+    save, 1 more pass equals one run of 3 passes; without the flag the behaviour stays the reference's."""
+    buf, side = str(tmp_path / "state.bin"), str(tmp_path / "state.rng")
+    common = ["-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf, "--rng-state", side]
+    r1 = run(exe, "--passes", "2", *common)
+    assert r1.returncode == 0
+    assert "File %s doesn't exist yet. Not loading." % side in r1.stdout
+    assert "Saving generator state to %s." % side in r1.stdout
+    r2 = run(exe, "--passes", "1", *common)
+    assert r2.returncode == 0
+    assert "Continuing the sample stream after 2 passes." in r2.stdout
+    three, _ = oracle.render(300, 200, 200, 20, T, 3, omp_threads=0)
+    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)
+    assert np.array_equal(state, three)
+    # a sidecar for another seed is refused
+    r3 = run(exe, "--passes", "1", "--seed", "99", *common)
+    assert r3.returncode == 1 and "is not a generator state for seed 99" in r3.stdout
+
+
+def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path):
+    buf = str(tmp_path / "seed.bin")
+    r = run(exe, "--passes", "1", "--seed", "4242", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 0
+    hist, _ = oracle.render(300, 200, 200, 20, T, 1, seed=4242, omp_threads=0)
+    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+
+
 def test_reference_format_u32_buffer_is_accepted_and_widened(exe, small_render, tmp_path):
     buf = str(tmp_path / "ref_state.bin")
     base = (np.arange(300 * 200, dtype=np.uint32) % 1000).reshape(200, 300)

@@ -308,3 +308,26 @@ def test_low_level_entry_points_on_torch_memory(cb, oracle):
     assert np.array_equal(st[5], ost["d"])
     for k in range(5):
         assert np.array_equal(st[k], ost["x"][:, k])
+
+
+def test_rng_states_round_trip_makes_a_true_resume(cb, oracle):
+    """N3: histogram + generator states are a complete checkpoint (cb_renderer_read/write_rng_states):
+    2 passes, checkpoint into a NEW renderer, 1 more pass == 3 passes in one go."""
+    w, h, t = 96, 64, 2048
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(400, 20)
+    with cb.Renderer(dims, it, n_threads=t) as r1:
+        r1.render_passes(2)
+        states = r1.read_rng_states()          # finishes the carried orbits first
+        hist = r1.read_histogram()
+    two, _ = oracle.render(w, h, 400, 20, t, 2)
+    assert np.array_equal(hist, two)
+    with cb.Renderer(dims, it, n_threads=t) as r2:
+        r2.write_histogram(hist)
+        r2.write_rng_states(states)
+        r2.render_passes(1)
+        resumed = r2.read_histogram()
+    three, _ = oracle.render(w, h, 400, 20, t, 3)
+    assert np.array_equal(resumed, three)
+    with pytest.raises(ValueError):
+        cb.Renderer(dims, it, n_threads=t).write_rng_states(states[:-1])
