@@ -75,6 +75,53 @@ __device__ __forceinline__ double mandel_step(double cr, double ci, double &r, d
   return __builtin_fma(ni, ni, nr * nr);
 }
 
+// ---- the same arithmetic on DOUBLED coordinates (draw_wave_kernel) ----------------------------------
+//
+// Scaling by a power of two commutes with IEEE rounding (no overflow; no result below 2^-1022, which
+// would take |z| < 2^-511), so with C = 2c, Z = 2z every rounded intermediate of the canonical
+// sequence has an exact image:
+//   II = I*I        = 4 (i*i)                    T  = fma(R,R,-II)  = 4 t
+//   NI = fma(R,I,CI) = 2 fma(r+r,i,ci)           NR = fma(T,0.5,CR) = 2 (cr + t)
+//   M  = fma(NI,NI,NR*NR) = 4 m,   tested against 16
+// The doubling r+r of the cross term comes for free: SIX fp64 instructions per step instead of seven,
+// the same bits (halved) in every register.  Cardioid and bulb tests scale the same way.
+__device__ __forceinline__ double sample_coordinate2(Xorwow &s) {  // 2 * sample_coordinate
+  const uint32_t v1 = xorwow_next(s);
+  const uint32_t v2 = xorwow_next(s);
+  const double lo = (double) v1;
+  const double hi = (double) (v2 >> 11);
+  const double v = __builtin_fma(hi, 4294967296.0, lo);
+  return __builtin_fma(v, 0x1p-50, 0x1p-50 - 4.0);
+}
+
+// in_main_cardioid(R/2, I/2): II = 4 im^2, X = 2 (re - 1/4), Q = 4 q, S = 4 (q + (re - 1/4)),
+// Q*S = 16 q (q + ...), and 16 * (im^2 / 4) = II.
+__device__ __forceinline__ bool in_main_cardioid2(double R, double I) {
+  const double II = I * I;
+  const double X = R - 0.5;
+  const double Q = __builtin_fma(X, X, II);
+  const double S = __builtin_fma(X, 2.0, Q);
+  return (Q * S) < II;
+}
+
+// in_order2_bulb(R/2, I/2): fma(T,T,II) = 4 fma(tmp,tmp,im^2), against 4/16.
+__device__ __forceinline__ bool in_order2_bulb2(double R, double I) {
+  const double II = I * I;
+  const double T = R + 2.0;
+  return __builtin_fma(T, T, II) < 0.25;
+}
+
+// mandel_step on doubled coordinates; returns 4 |z|^2 (escape: > 16).
+__device__ __forceinline__ double mandel_step2(double CR, double CI, double &R, double &I) {
+  const double II = I * I;
+  const double T = __builtin_fma(R, R, -II);
+  const double NI = __builtin_fma(R, I, CI);
+  const double NR = __builtin_fma(T, 0.5, CR);
+  R = NR;
+  I = NI;
+  return __builtin_fma(NI, NI, NR * NR);
+}
+
 // Canvas geometry as the kernels consume it: FractalDimensions (cudabrot.cu:46-58) plus the exact
 // reciprocal fast path of SURVEY.md H3.
 struct Canvas {

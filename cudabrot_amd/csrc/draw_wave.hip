@@ -30,7 +30,12 @@
 //           device-scope u64 atomics without a workspace).  Lanes refill from Q2 as they finish; a
 //           replay in flight is suspended (state stays in registers) while too few lanes are busy.
 //
-// All step loops are hand-written gfx950 assembly: per iteration 7 fp64 VALU instructions + one
+// Every coordinate in this kernel (c and z in registers, queues and the carry buffer) is DOUBLED:
+// C = 2c, Z = 2z.  Scaling by two is exact, every rounded intermediate of the canonical sequence has
+// an exact image, and the doubling r+r of the cross term disappears (device_math.h, mandel_step2):
+// six fp64 instructions per step instead of seven, the same results.
+//
+// All step loops are hand-written gfx950 assembly: per iteration 6 fp64 VALU instructions + one
 // compare and 2-3 scalar instructions for the exact lane-step count.  The compiler's own lowering of
 // the same loops spent ~35 scalar instructions per step on mask bookkeeping, and the one scalar
 // unit of a CU serves all four SIMDs.
@@ -77,21 +82,21 @@ __device__ __forceinline__ double uniform_f64(double v) {
 
 // ---- one orbit per lane under EXEC (HEAD, MID, the last short chunk of LONG) -----------------------
 //
-// One z <- z^2 + c step on the lanes in EXEC, in the canonical order of device_math.h's mandel_step:
-//   a = i*i; b = r+r; a = fma(r,r,-a); i = fma(b,i,ci); r = cr + a; a = r*r; a = fma(i,i,a)
-// then EXEC &= !(4.0 < a) (v_cmpx: a lane leaves at its escape, cudabrot.cu:336), after adding the
-// number of lanes that execute the step to the scalar counter.
+// One z <- z^2 + c step on the lanes in EXEC, on DOUBLED coordinates, in the order of
+// device_math.h's mandel_step2:
+//   a = i*i; a = fma(r,r,-a); i = fma(r,i,ci); r = fma(a,0.5,cr); a = r*r; a = fma(i,i,a)
+// then EXEC &= !(16.0 < a) (v_cmpx: a lane leaves at its escape, cudabrot.cu:336), after adding the
+// number of lanes that execute the step to the scalar counter.  k16 is 16.0 in a scalar pair.
 #define CB_STEP                                       \
   "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
-  "v_add_f64 %[b], %[r], %[r]\n\t"                    \
   "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
-  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"             \
-  "v_add_f64 %[r], %[cr], %[a]\n\t"                   \
+  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
-  "v_cmpx_nlt_f64_e32 vcc, 4.0, %[a]\n\t"
+  "v_cmpx_nlt_f64_e32 vcc, %[k16], %[a]\n\t"
 
 // n steps (wave-uniform run-time count) on the lanes of `mask`, leaving early once every lane has
 // escaped.  Returns the lanes that escaped; r, i of the others advance by n iterations; lane_steps
@@ -100,7 +105,8 @@ __device__ __forceinline__ unsigned long long iterate_steps(unsigned long long m
                                                             Orbit &o, uint32_t &lane_steps) {
   unsigned long long save, escaped;
   uint32_t cnt, tmp, ctr;
-  double a, b;
+  double a;
+  const double k16 = 16.0;
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b32 %[cnt], 0\n\t"
@@ -118,9 +124,9 @@ __device__ __forceinline__ unsigned long long iterate_steps(unsigned long long m
       "s_andn2_b64 %[esc], %[mask], exec\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "s_nop 4\n\t"
-      : [r] "+v"(o.r), [i] "+v"(o.i), [a] "=&v"(a), [b] "=&v"(b), [save] "=&s"(save),
+      : [r] "+v"(o.r), [i] "+v"(o.i), [a] "=&v"(a), [save] "=&s"(save),
         [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr)
-      : [mask] "s"(mask), [n] "s"(n), [cr] "v"(o.cr), [ci] "v"(o.ci)
+      : [mask] "s"(mask), [n] "s"(n), [cr] "v"(o.cr), [ci] "v"(o.ci), [k16] "s"(k16)
       : "vcc", "scc");
   lane_steps = cnt;
   return escaped;
@@ -158,7 +164,7 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
 // instruction: the step is a chain of ~6 dependent fp64 operations, and a SIMD whose waves drift
 // apart must be able to fill the fp64 pipe from few waves.  Measured with this very chunk on MI355X
 // (tools/microbench.hip): 84.5 % of fp64 issue peak at 4 waves per SIMD, 60 % from a single wave
-// (one orbit per lane: 58 % / 32 %).
+// (one orbit per lane: 58 % / 32 %; measured with the seven-instruction form of the step).
 //
 // Two orbit sets cannot share one EXEC mask, so EXEC stays untouched: every lane computes every
 // step (an idle or already escaped slot computes garbage that nothing reads) and the orbits still
@@ -171,25 +177,23 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
   "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
   "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
   "s_and_b64 %[la], %[la], %[c0]\n\t"                     \
-  "v_add_f64 %[b0], %[ra], %[ra]\n\t"                     \
-  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
-  "v_add_f64 %[b1], %[rb], %[rb]\n\t"                     \
-  "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
   "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
-  "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
+  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
   "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
+  "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
+  "v_fma_f64 %[ia], %[ra], %[ia], %[cia]\n\t"             \
+  "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
+  "v_fma_f64 %[ib], %[rb], %[ib], %[cib]\n\t"             \
   "s_add_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
-  "v_fma_f64 %[ia], %[b0], %[ia], %[cia]\n\t"             \
+  "v_fma_f64 %[ra], %[a0], 0.5, %[cra]\n\t"               \
   "s_add_u32 %[cnt], %[cnt], %[t1]\n\t"                   \
-  "v_fma_f64 %[ib], %[b1], %[ib], %[cib]\n\t"             \
-  "v_add_f64 %[ra], %[cra], %[a0]\n\t"                    \
-  "v_add_f64 %[rb], %[crb], %[a1]\n\t"                    \
+  "v_fma_f64 %[rb], %[a1], 0.5, %[crb]\n\t"               \
   "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
   "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
   "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
   "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
-  "v_cmp_nlt_f64_e64 %[c0], 4.0, %[a0]\n\t"               \
-  "v_cmp_nlt_f64_e64 %[c1], 4.0, %[a1]\n\t"
+  "v_cmp_nlt_f64_e64 %[c0], %[k16], %[a0]\n\t"            \
+  "v_cmp_nlt_f64_e64 %[c1], %[k16], %[a1]\n\t"
 #define CB_STEP2X4 CB_STEP2 CB_STEP2 CB_STEP2 CB_STEP2
 #define CB_STEP2X32 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
 
@@ -203,7 +207,8 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   static_assert(kChunk == 32, "CB_STEP2X32 is unrolled for 32 steps");
   unsigned long long la = mask_a, lb = mask_b, c0, c1;
   uint32_t cnt, t0, t1;
-  double a0, a1, b0, b1;
+  double a0, a1;
+  const double k16 = 16.0;
   asm volatile(
       "s_mov_b32 %[cnt], 0\n\t"
       "s_mov_b64 %[c0], -1\n\t"
@@ -212,9 +217,9 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
       "s_and_b64 %[la], %[la], %[c0]\n\t"
       "s_and_b64 %[lb], %[lb], %[c1]\n\t"
       : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [la] "+s"(la),
-        [lb] "+s"(lb), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1),
+        [lb] "+s"(lb), [a0] "=&v"(a0), [a1] "=&v"(a1),
         [c0] "=&s"(c0), [c1] "=&s"(c1), [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)
-      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci)
+      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci), [k16] "s"(k16)
       : "scc");
   esc_a = mask_a & ~la;
   esc_b = mask_b & ~lb;
@@ -223,20 +228,25 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 
 // ---- REPLAY burst: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream --------------------
 //
-// One step for the lanes of `act` (EXEC), in the order of the reference's loop body:
-//   z <- z^2 + c            (CB_STEP's seven fp64 instructions, same order)
+// One step for the lanes of `act` (EXEC), in the order of the reference's loop body, on doubled
+// coordinates (R = 2 re, I = 2 im):
+//   z <- z^2 + c            (CB_STEP's six fp64 instructions, same order)
 //   IncrementPixelCounter   if (re >= min_re && im >= min_im) { col = (int)((re-min_re)/d_re); row
 //                           likewise; if (col <u w && row <u h) append row<<16|col to the stream }
 //                           (cudabrot.cu:308-312; the unsigned compares also reject the saturated
 //                           conversions, and col, row cannot be negative past the first test)
 //   if (|z|^2 > 4) leave    (cudabrot.cu:363) -- after recording the escaped point, like the reference
-// The hits of a step are compacted with v_mbcnt and stored side by side (one coalesced store).
-// x / delta: an exact multiply when both deltas are powers of two (CB_REPLAY_BIN_POW2), else the
-// correctly rounded IEEE quotient by the same instruction sequence hipcc emits for a double
-// division (CB_REPLAY_BIN_DIV: v_div_scale / v_rcp / Newton steps / v_div_fmas / v_div_fixup).
+// re - min_re = fma(R, 0.5, -min_re) exactly (halving is exact).  (re - min_re) / d_re:
+//   CB_REPLAY_BIN_POW2  both deltas are powers of two: the quotient is (re - min_re) * (1/d) exactly
+//                       and, scaling being exact, equals the single fma(R, 0.5/d, -min_re/d);
+//   CB_REPLAY_BIN_DIV   else the correctly rounded IEEE quotient by the instruction sequence hipcc
+//                       emits for a double division (v_div_scale / v_rcp / Newton steps /
+//                       v_div_fmas / v_div_fixup).
+// The tests re >= min_re, im >= min_im are made on the doubled values (R >= 2 min_re).  The hits of a
+// step are compacted with v_mbcnt and stored side by side (one coalesced store).
 #define CB_REPLAY_BIN_POW2                                \
-  "v_mul_f64 %[fx], %[fx], %[sx]\n\t"                     \
-  "v_mul_f64 %[fy], %[fy], %[sy]\n\t"
+  "v_fma_f64 %[fx], %[r], %[sx], %[ox]\n\t"               \
+  "v_fma_f64 %[fy], %[i], %[sy], %[oy]\n\t"
 #define CB_DIV(q, num, den)                                         \
   "v_div_scale_f64 %[d0], %[scp], " den ", " den ", " num "\n\t"    \
   "v_rcp_f64 %[d2], %[d0]\n\t"                                      \
@@ -249,7 +259,10 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   "v_fma_f64 %[d0], -%[d0], %[d3], %[d1]\n\t"                       \
   "v_div_fmas_f64 %[d0], %[d0], %[d2], %[d3]\n\t"                   \
   "v_div_fixup_f64 " q ", %[d0], " den ", " num "\n\t"
-#define CB_REPLAY_BIN_DIV CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]")
+#define CB_REPLAY_BIN_DIV                                 \
+  "v_fma_f64 %[fx], %[r], 0.5, -%[ox]\n\t"                \
+  "v_fma_f64 %[fy], %[i], 0.5, -%[oy]\n\t"                \
+  CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]")
 
 #define CB_REPLAY_HEAD                                    \
   "s_mov_b64 %[save], exec\n\t"                           \
@@ -260,22 +273,19 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   "s_mov_b64 exec, %[act]\n\t"                            \
   "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
-  "v_add_f64 %[b], %[r], %[r]\n\t"                        \
   "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
-  "v_fma_f64 %[i], %[b], %[i], %[ci]\n\t"                 \
-  "v_add_f64 %[r], %[cr], %[a]\n\t"                       \
+  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"                 \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_add_u32 %[ps], 1, %[ps]\n\t"                         \
-  "v_add_f64 %[fy], %[i], -%[miny]\n\t"                   \
+  "v_cmp_le_f64_e64 %[hy], %[miny2], %[i]\n\t"            \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
-  "v_add_f64 %[fx], %[r], -%[minx]\n\t"                   \
-  "v_cmp_le_f64_e64 %[hy], %[miny], %[i]\n\t"             \
-  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
-  "v_cmp_le_f64_e64 %[hx], %[minx], %[r]\n\t"
+  "v_cmp_le_f64_e64 %[hx], %[minx2], %[r]\n\t"            \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
 #define CB_REPLAY_TAIL                                    \
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
-  "v_cmp_nlt_f64_e64 %[alive], 4.0, %[a]\n\t"             \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
   "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
   "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
@@ -302,48 +312,52 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 
 // Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for
 // 64 * n_steps more entries.  On return `act` holds the lanes still replaying, `fill` the new fill,
-// lane_steps / hits the executed lane-steps and the entries appended.
+// lane_steps / hits the executed lane-steps and the entries appended.  p holds DOUBLED coordinates.
 template <bool kPow2>
 __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                              int &p_steps, const Canvas &cv, uint32_t *region,
                                              uint32_t &fill, uint32_t &lane_steps, uint32_t &hits) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
-  double a, b, fx, fy, d0, d1, d2, d3;
+  double a, fx, fy, d0, d1, d2, d3;
   uint32_t col, row, pidx, e;
-  // x / delta as an exact multiply (kPow2) or a true division: the scale operands.  All "s"
-  // operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
-  const double sx = uniform_f64(kPow2 ? cv.inv_delta_real : cv.delta_real);
-  const double sy = uniform_f64(kPow2 ? cv.inv_delta_imag : cv.delta_imag);
-  const double minx = uniform_f64(cv.min_real), miny = uniform_f64(cv.min_imag);
+  // All "s" operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
+  const double minx2 = uniform_f64(cv.min_real + cv.min_real), miny2 = uniform_f64(cv.min_imag + cv.min_imag);
   const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t) cv.w);
   const uint32_t h = __builtin_amdgcn_readfirstlane((uint32_t) cv.h);
   region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  const double k16 = 16.0;
   if (kPow2) {
+    // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
+    // a VALU instruction reads one scalar operand
+    const double sx = uniform_f64(0.5 * cv.inv_delta_real), sy = uniform_f64(0.5 * cv.inv_delta_imag);
+    const double ox = -(cv.min_real * cv.inv_delta_real), oy = -(cv.min_imag * cv.inv_delta_imag);
     asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
-                   [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
-                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
-                   [base] "s"(region)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16)
                  : "vcc", "scc", "memory");
   } else {
+    const double sx = uniform_f64(cv.delta_real), sy = uniform_f64(cv.delta_imag);
+    const double ox = uniform_f64(cv.min_real), oy = uniform_f64(cv.min_imag);
     asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
-                   [a] "=&v"(a), [b] "=&v"(b), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
                    [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx] "s"(minx),
-                   [miny] "s"(miny), [sx] "s"(sx), [sy] "s"(sy), [w] "s"(w), [h] "s"(h),
-                   [base] "s"(region)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16)
                  : "vcc", "scc", "memory");
   }
   lane_steps = cs;
@@ -504,11 +518,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
           bool done = false, hit = false;
           int row = 0, col = 0;
           if (p_act) {
-            const double m = mandel_step(po.cr, po.ci, po.r, po.i);   // cudabrot.cu:357-359
-            hit = pixel_of(po.r, po.i, cv, row, col);                 // cudabrot.cu:308-311
-            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);        // cudabrot.cu:312
+            const double m4 = mandel_step2(po.cr, po.ci, po.r, po.i);  // cudabrot.cu:357-359
+            hit = pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);      // cudabrot.cu:308-311 (halving is exact)
+            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);         // cudabrot.cu:312
             p_steps++;
-            done = m > 4.0;                                           // cudabrot.cu:363
+            done = m4 > 16.0;                                          // cudabrot.cu:363
             if (!done && p_steps > max_iter) {
               status |= CB_STATUS_REPLAY_RUNAWAY;
               done = true;
@@ -532,9 +546,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
       bool alive = false;
       Orbit o = {0, 0, 0, 0};
       if (valid) {
-        o.cr = sample_coordinate(rng);  // cudabrot.cu:392
-        o.ci = sample_coordinate(rng);  // cudabrot.cu:393
-        alive = !(in_main_cardioid(o.cr, o.ci) || in_order2_bulb(o.cr, o.ci));  // cudabrot.cu:398
+        o.cr = sample_coordinate2(rng);  // cudabrot.cu:392 (doubled, like everything below)
+        o.ci = sample_coordinate2(rng);  // cudabrot.cu:393
+        alive = !(in_main_cardioid2(o.cr, o.ci) || in_order2_bulb2(o.cr, o.ci));  // cudabrot.cu:398
       }
       o.r = o.cr;
       o.i = o.ci;
