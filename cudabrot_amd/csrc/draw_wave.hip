@@ -158,6 +158,219 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
   return accepted;
 }
 
+// ---- HEAD in one piece (head_steps == 4 <= min_iter) -----------------------------------------------
+//
+// Every sample passes through HEAD, so its instruction count is a tenth of the kernel's.  Two asm
+// blocks:
+//   head_draw   four XORWOW outputs (rocrand_xorwow.h:165-177) and the two starting coordinates
+//               (device_math.h, sample_coordinate2), 8 + 5 VALU instructions per output pair half.
+//               The generator's five words rotate by one place per output; instead of moving
+//               registers the block is instantiated for the five rotations (ROT) and the kernel
+//               keeps the current rotation in a scalar: logical word j lives in field (j + rot) % 5.
+//   head_test   cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first four
+//               iterations under EXEC; the rounded I*I of the tests is the first product of step 1.
+template <int K>
+__device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
+  static_assert(K >= 0 && K < 5, "five words");
+  if constexpr (K == 0) return s.x0;
+  if constexpr (K == 1) return s.x1;
+  if constexpr (K == 2) return s.x2;
+  if constexpr (K == 3) return s.x3;
+  return s.x4;
+}
+
+// One output: xk is the oldest word (x0 of rocrand's step), xp the newest (x4); the new word
+// replaces xk (which also serves as a temporary once t is formed); out = d + k * 362437 + new word
+// (the multiple of the Weyl increment goes through one scratch scalar).
+#define CB_XW_DRAW(xk, xp, out, ck)                      \
+  "v_lshrrev_b32 %[t], 2, " xk "\n\t"                    \
+  "v_lshlrev_b32 %[u], 4, " xp "\n\t"                    \
+  "s_mov_b32 %[sc], " ck "\n\t"                          \
+  "v_xor_b32 %[t], %[t], " xk "\n\t"                     \
+  "v_xor_b32 %[u], %[u], " xp "\n\t"                     \
+  "v_lshlrev_b32 " xk ", 1, %[t]\n\t"                    \
+  "v_xor_b32 %[t], %[t], " xk "\n\t"                     \
+  "v_xor_b32 " xk ", %[u], %[t]\n\t"                     \
+  "v_add3_u32 " out ", v125, " xk ", %[sc]\n\t"
+// C = fma(fma(hi, 2^32, lo), 2^-50, 2^-50 - 4) with lo = o1, hi = o2 >> 11 (0x41f00000: the high word
+// of 2^32 as the literal of a VOP2 fmac)
+#define CB_XW_COORD(c)                                   \
+  "v_cvt_f64_u32 " c ", %[o1]\n\t"                       \
+  "v_lshrrev_b32 %[o2], 11, %[o2]\n\t"                   \
+  "v_cvt_f64_u32 %[f], %[o2]\n\t"                        \
+  "v_fmac_f64_e32 " c ", 0x41f00000, %[f]\n\t"           \
+  "v_fma_f64 " c ", " c ", %[k2m50], v[126:127]\n\t"
+// Four outputs and both coordinates; X0..X4 = the registers of the logical words x0..x4.
+#define CB_HEAD_DRAW(X0, X1, X2, X3, X4)                 \
+  CB_XW_DRAW(X0, X4, "%[o1]", "0x587c5")                 \
+  CB_XW_DRAW(X1, X0, "%[o2]", "0xb0f8a")                 \
+  CB_XW_COORD("%[cr]")                                   \
+  CB_XW_DRAW(X2, X1, "%[o1]", "0x10974f")                \
+  CB_XW_DRAW(X3, X2, "%[o2]", "0x161f14")                \
+  "v_add_u32 v125, %[sc], v125\n\t"                      \
+  CB_XW_COORD("%[ci]")
+static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u == 0x10974fu &&
+                  4u * 362437u == 0x161f14u,
+              "multiples of the Weyl increment (rocrand_xorwow.h:174)");
+
+// rot: logical word j lives in register v[120 + (j + rot) % 5].  In the kernels that use this block
+// the generator lives in v120..v125 (five words and the Weyl value) and v[126:127] holds the constant
+// 2^-50 - 4 for the whole launch: the kernel is compiled with a budget of 120 vector registers
+// (amdgpu_num_vgpr), so the compiler never touches them, and no copy in or out of the block is
+// needed (as operands the six words were copied to fresh registers and back on every pass).
+// One statement holds the text for the five rotations behind scalar branches; it also steps rot.
+#define CB_V_X0 "v120"
+#define CB_V_X1 "v121"
+#define CB_V_X2 "v122"
+#define CB_V_X3 "v123"
+#define CB_V_X4 "v124"
+#define CB_HEAD_RESERVED "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+__device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci) {
+  uint32_t t, u, o1, o2, sc, next;
+  double f;
+  asm volatile(
+      "s_cmp_lt_u32 %[rot], 2\n\t"
+      "s_cbranch_scc1 11f\n\t"
+      "s_cmp_eq_u32 %[rot], 2\n\t"
+      "s_cbranch_scc1 12f\n\t"
+      "s_cmp_eq_u32 %[rot], 3\n\t"
+      "s_cbranch_scc1 13f\n\t"
+      CB_HEAD_DRAW(CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3)  // rot 4
+      "s_branch 19f\n\t"
+      "13:\n\t"
+      CB_HEAD_DRAW(CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2)
+      "s_branch 19f\n\t"
+      "12:\n\t"
+      CB_HEAD_DRAW(CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1)
+      "s_branch 19f\n\t"
+      "11:\n\t"
+      "s_cmp_eq_u32 %[rot], 0\n\t"
+      "s_cbranch_scc1 10f\n\t"
+      CB_HEAD_DRAW(CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0)
+      "s_branch 19f\n\t"
+      "10:\n\t"
+      CB_HEAD_DRAW(CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4)
+      "19:\n\t"
+      // four outputs later the words sit four places on: rot <- (rot + 4) % 5
+      "s_add_u32 %[next], %[rot], 4\n\t"
+      "s_sub_u32 %[sc], %[rot], 1\n\t"
+      "s_cmp_ge_u32 %[next], 5\n\t"
+      "s_cselect_b32 %[next], %[sc], %[next]\n\t"
+      : [cr] "=&v"(cr), [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1),
+        [o2] "=&v"(o2), [f] "=&v"(f), [sc] "=&s"(sc), [next] "=&s"(next)
+      : [rot] "s"(rot), [k2m50] "s"(0x1p-50)
+      : "scc", CB_HEAD_RESERVED);
+  rot = next;
+}
+
+// The reserved registers: load at the start of a launch (logical order, rot = 0) ...
+__device__ __forceinline__ void head_registers_load(const Xorwow &s) {
+  asm volatile(
+      "v_mov_b32 v120, %[x0]\n\t"
+      "v_mov_b32 v121, %[x1]\n\t"
+      "v_mov_b32 v122, %[x2]\n\t"
+      "v_mov_b32 v123, %[x3]\n\t"
+      "v_mov_b32 v124, %[x4]\n\t"
+      "v_mov_b32 v125, %[d]\n\t"
+      "v_mov_b32 v126, 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
+      "v_mov_b32 v127, 0xc00fffff\n\t"
+      :
+      : [x0] "v"(s.x0), [x1] "v"(s.x1), [x2] "v"(s.x2), [x3] "v"(s.x3), [x4] "v"(s.x4), [d] "v"(s.d)
+      : CB_HEAD_RESERVED);
+}
+// ... and read back at its end (fields as the registers hold them: logical word j in field (j + rot) % 5).
+__device__ __forceinline__ Xorwow head_registers_read() {
+  Xorwow s;
+  asm volatile(
+      "v_mov_b32 %[x0], v120\n\t"
+      "v_mov_b32 %[x1], v121\n\t"
+      "v_mov_b32 %[x2], v122\n\t"
+      "v_mov_b32 %[x3], v123\n\t"
+      "v_mov_b32 %[x4], v124\n\t"
+      "v_mov_b32 %[d], v125\n\t"
+      : [x0] "=v"(s.x0), [x1] "=v"(s.x1), [x2] "=v"(s.x2), [x3] "=v"(s.x3), [x4] "=v"(s.x4),
+        [d] "=v"(s.d));
+  return s;
+}
+
+// The generator words in logical order again (rot back to 0), for store_rng and the generic HEAD.
+template <int ROT>
+__device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
+  Xorwow r;
+  r.x0 = xorwow_word<(0 + ROT) % 5>(s);
+  r.x1 = xorwow_word<(1 + ROT) % 5>(s);
+  r.x2 = xorwow_word<(2 + ROT) % 5>(s);
+  r.x3 = xorwow_word<(3 + ROT) % 5>(s);
+  r.x4 = xorwow_word<(4 + ROT) % 5>(s);
+  r.d = s.d;
+  return r;
+}
+
+// Cardioid / bulb test and iterations 0..3 of the lanes in `valid`, then the survivors' c goes to Q0
+// (slot (q0_tail + rank) & 127 of the ring at LDS byte address q0_lds: q0_cr there, q0_ci 1024 bytes
+// on).  alive0: lanes outside both regions (cudabrot.cu:398); alive4: lanes that have not escaped
+// after four steps; lane_steps: the iterations the reference executes for these samples up to there.
+// 0x3fd00000 / 0x40300000: the high words of 0.25 and 16.0 as VOPC literals.
+#define CB_STEP_LIT                                   \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
+__device__ __forceinline__ void head_test(unsigned long long valid, double cr, double ci,
+                                          uint32_t q0_tail, uint32_t q0_lds,
+                                          unsigned long long &alive0, unsigned long long &alive4,
+                                          uint32_t &lane_steps) {
+  static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci below");
+  unsigned long long save;
+  uint32_t cnt, tmp, slot;
+  double a, r, i, x, q;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, %[valid]\n\t"
+      "v_mul_f64 %[a], %[ci], %[ci]\n\t"             // II
+      "v_add_f64 %[x], %[cr], -0.5\n\t"              // X = 2 (re - 1/4)
+      "v_add_f64 %[r], %[cr], 2.0\n\t"               // T = 2 (re + 1)
+      "v_fma_f64 %[q], %[x], %[x], %[a]\n\t"         // Q
+      "v_fma_f64 %[r], %[r], %[r], %[a]\n\t"         // bulb: fma(T,T,II)
+      "v_fma_f64 %[x], %[x], 2.0, %[q]\n\t"          // S
+      "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t"  // !(bulb < 1/4)
+      "v_mul_f64 %[q], %[q], %[x]\n\t"               // Q * S
+      "s_mov_b64 %[alive0], vcc\n\t"
+      "v_cmp_nlt_f64_e64 %[alive4], %[q], %[a]\n\t"  // !(Q*S < II)
+      "s_and_b64 %[alive0], %[alive0], %[alive4]\n\t"
+      "s_mov_b64 exec, %[alive0]\n\t"
+      "s_bcnt1_i32_b64 %[cnt], %[alive0]\n\t"
+      // step 1 from z = c; its first product I*I is II
+      "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
+      "v_fma_f64 %[i], %[cr], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+      "v_mul_f64 %[a], %[r], %[r]\n\t"
+      "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
+      "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
+      CB_STEP_LIT CB_STEP_LIT CB_STEP_LIT
+      "s_mov_b64 %[alive4], exec\n\t"
+      // survivors (EXEC) -> Q0
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
+      "v_add_u32 %[slot], %[tail], %[slot]\n\t"
+      "v_and_b32 %[slot], 0x7f, %[slot]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[lds]\n\t"
+      "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [alive0] "=&s"(alive0), [alive4] "=&s"(alive4), [cnt] "=&s"(cnt), [save] "=&s"(save),
+        [tmp] "=&s"(tmp), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x), [q] "=&v"(q),
+        [slot] "=&v"(slot)
+      : [valid] "s"(valid), [cr] "v"(cr), [ci] "v"(ci), [tail] "v"(q0_tail), [lds] "s"(q0_lds)
+      : "vcc", "scc", "memory");
+  lane_steps = cnt;
+}
+
 // ---- two orbits per lane, EXEC untouched (LONG) ----------------------------------------------------
 //
 // The LONG stage keeps TWO independent orbits (A and B) per lane and interleaves them instruction by
@@ -367,8 +580,9 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
 // ring index helper for the 192-entry Q2
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
-template <bool kTimed, bool kBinned>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs a) {
+template <bool kTimed, bool kBinned, bool kFastHead>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(120)))
+draw_wave_kernel(DrawArgs a) {
   static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
   __shared__ WaveQueues queues[kWavesPerBlock];
   WaveQueues &q = queues[threadIdx.x >> 6];
@@ -394,6 +608,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
 
   Xorwow rng = {0, 0, 0, 0, 0, 0};
   if (valid) rng = load_rng(a.states, a.n_threads, tid);
+  if constexpr (kFastHead) head_registers_load(rng);  // the generator lives in v120..v125 from here on
 
   // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t samples_left = a.samples_per_thread;
@@ -409,6 +624,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
   // wave slot on its SIMD (HW_REG_HW_ID bits 3:0) and chunks done, for the priority rotation
   const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));
   uint32_t long_chunks = 0;
+  // HEAD as one asm block (head_draw / head_test): the usual stage split, where every escape inside
+  // HEAD is too fast and survivors always have iterations left
+  // (launch_draw_wave picks the instance; a kernel holds one of the two HEAD forms so that the
+  // generator words have a single user and stay in place)
+  constexpr bool fast_head = kFastHead;
+  uint32_t rot = 0;  // rotation of the generator words, see head_draw
+  // LDS byte address of this wave's Q0 ring (the low half of a flat LDS address is the LDS offset)
+  const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
   // LONG lane state: two orbits per lane (see CB_STEP2)
   Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
@@ -539,10 +763,37 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
     }
     if (draining) break;
 
+    // HEAD and MID feed the queues in a loop of their own, in the same order of precedence as the
+    // outer loop (REPLAY > HEAD > MID > LONG): they run far more often than the other stages, and
+    // inside this loop only the generator and the queue counters are live-modified, so its back
+    // edge is light (the outer loop's carries every orbit register).
+    bool replay_ready = false;
+    for (;;) {
+    if (q2_count > 0 && q2_count + n_replaying >= 64) {
+      replay_ready = true;
+      break;
+    }
+    const bool feed_input_done = (samples_left == 0);
+    if (feed_input_done && carry && !a.drain) break;  // the rest is left in the queues for the next launch
     // ---------------------------------------------------------------- HEAD
-    if (!input_done && q0_count < 64) {
+    if (!feed_input_done && q0_count < 64) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       samples_left--;
+      if constexpr (fast_head) {  // the usual split (plan_stages): one asm block each for the draw and the test
+        double c_re, c_im;
+        head_draw(rot, c_re, c_im);  // cudabrot.cu:392-393
+        unsigned long long alive0, alive4;
+        uint32_t steps;
+        head_test(valid_mask, c_re, c_im, (uint32_t) (q0_head + q0_count), q0_lds, alive0, alive4,
+                  steps);  // cudabrot.cu:398, 326-337; survivors -> Q0
+        n_rejected += (unsigned long long) __popcll(valid_mask & ~alive0);
+        n_iterate += steps;
+        n_too_fast += (unsigned long long) __popcll(alive0 & ~alive4);  // escaped before min_iter
+        q0_count += __popcll(alive4);
+        if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
+        continue;
+      }
       bool alive = false;
       Orbit o = {0, 0, 0, 0};
       if (valid) {
@@ -583,7 +834,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
     }
 
     // ---------------------------------------------------------------- MID
-    if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || input_done)) {
+    if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       const int n = q0_count < 64 ? q0_count : 64;
       const bool mine = lane_id() < n;
@@ -631,6 +882,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
       if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
       continue;
     }
+    break;
+    }  // feed loop
+    if (replay_ready) continue;
+    if (samples_left == 0 && carry && !a.drain) continue;  // leaves at the top: nothing drawn is lost
 
     // ---------------------------------------------------------------- LONG
     const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -757,6 +1012,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) draw_wave_kernel(DrawArgs
     if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
   }
 
+  if constexpr (kFastHead) rng = head_registers_read();
+  switch (rot) {  // back to the logical order of the generator words
+    case 1: rng = xorwow_unrotated<1>(rng); break;
+    case 2: rng = xorwow_unrotated<2>(rng); break;
+    case 3: rng = xorwow_unrotated<3>(rng); break;
+    case 4: rng = xorwow_unrotated<4>(rng); break;
+    default: break;
+  }
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
   if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
   if (carry) {  // leave queues and orbit slots for the next launch (empty after a drain)
@@ -836,15 +1099,25 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   const uint32_t blocks = (a.n_threads + threads - 1u) / threads;
   const bool binned = a.bin.enabled != 0u;
   if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
-  if (timed && binned) {
-    hipLaunchKernelGGL((draw_wave_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
-  } else if (timed) {
-    hipLaunchKernelGGL((draw_wave_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
-  } else if (binned) {
-    hipLaunchKernelGGL((draw_wave_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
+  // HEAD as one asm block needs the usual stage split: every escape inside HEAD is too fast and
+  // survivors always have iterations left
+  const bool fast = (a.head_steps == 4) && (a.min_iter >= 4) && (a.max_iter > 4);
+  const dim3 grid(blocks), block(threads);
+#define CB_LAUNCH(T, B, F) hipLaunchKernelGGL((draw_wave_kernel<T, B, F>), grid, block, 0, stream, a)
+  if (timed) {
+    if (binned) {
+      if (fast) CB_LAUNCH(true, true, true); else CB_LAUNCH(true, true, false);
+    } else {
+      if (fast) CB_LAUNCH(true, false, true); else CB_LAUNCH(true, false, false);
+    }
   } else {
-    hipLaunchKernelGGL((draw_wave_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
+    if (binned) {
+      if (fast) CB_LAUNCH(false, true, true); else CB_LAUNCH(false, true, false);
+    } else {
+      if (fast) CB_LAUNCH(false, false, true); else CB_LAUNCH(false, false, false);
+    }
   }
+#undef CB_LAUNCH
   return hipGetLastError();
 }
 
