@@ -68,8 +68,10 @@ struct Orbit {
   double cr, ci, r, i;
 };
 
+// This lane's bit of a wave-uniform mask, as a predicate: the mask itself becomes the condition
+// register (s_and_saveexec), no vector instruction.
 __device__ __forceinline__ bool lane_in(unsigned long long mask) {
-  return (mask >> lane_id()) & 1ull;
+  return __builtin_amdgcn_inverse_ballot_w64(mask);
 }
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v);
@@ -995,8 +997,8 @@ draw_wave_kernel(DrawArgs a) {
             l_rem[o] = 0;
             ended = true;
           } else {
-            const int chunks_done = (long_steps - l_rem[o]) / kChunk;
-            if ((chunks_done & (chunks_done - 1)) == 0) {
+            const uint32_t chunks_done = (uint32_t) (long_steps - l_rem[o]) / (uint32_t) kChunk;
+            if ((chunks_done & (chunks_done - 1u)) == 0u) {
               seen_r[o] = lo[o].r;
               seen_i[o] = lo[o].i;
             }
