@@ -37,6 +37,7 @@ PASSES_PER_STEP = 64
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (spec)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_ITERATION = 10         # 6 mul + 4 add/sub of cudabrot.cu:331-336
+ISSUE_SLOTS_PER_ITERATION = 7    # what the kernel issues per iteration: 6 fp64 instructions (doubled-coordinate step) + 1 compare
 BYTES_PER_INCREMENT = 16         # u64 read + write per histogram increment
 
 
@@ -276,7 +277,7 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
-                "issue_frac": round(tflops / FLOPS_PER_ITERATION * 8 / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+                "issue_frac": round(tflops / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_flops_per_launch": iters_per_launch * FLOPS_PER_ITERATION,
                 "traffic": traffic["draw"] if traffic else None,
@@ -285,8 +286,9 @@ def main():
                         "the kernel EXECUTED (counted in-kernel; orbits found exactly periodic are retired early "
                         "with the identical outcome, so at max_iter=20000 only ~14 % of the reference's iterations "
                         "are executed); the kernel also draws, tests and replays, so this is a lower bound on its "
-                        "fp64 use; ceiling of `frac` for the 7-op+compare sequence is 0.625; issue_frac = fp64 "
-                        "issue-slot utilisation (8 per iteration)",
+                        "fp64 use; the kernel executes an iteration as 6 fp64 instructions + 1 compare "
+                        "(doubled-coordinate form of the 10-flop step), so the ceiling of `frac` is 10/14 = 0.714; "
+                        "issue_frac = fp64 issue-slot utilisation (7 per iteration)",
             },
             "roofline_scatter": {
                 "bound": "hbm",
@@ -329,7 +331,7 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
-                "issue_frac": round(ftf / FLOPS_PER_ITERATION * 8 / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+                "issue_frac": round(ftf / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(fms, 4),
                 "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
             }
