@@ -373,6 +373,69 @@ __device__ __forceinline__ void head_test(unsigned long long valid, double cr, d
   lane_steps = cnt;
 }
 
+// ---- MID in one piece (every escape inside MID is too fast, survivors go on to LONG) ---------------
+//
+// The lanes of `take` pop c from Q0 (ring slot (q0_head + lane) & 127 at LDS byte address q0_lds),
+// re-derive z after the four HEAD iterations (Q0 keeps only c; no escape is possible there, so no
+// compare), run n_steps more iterations under EXEC and push the survivors' (c, z) to Q1 (ring slot
+// (q1_tail + rank) & 127 at q1_lds; q1_ci, q1_r, q1_i follow at 1024-byte distances).  lane_steps:
+// the executed iterations of the n_steps window; alive: the survivors.
+#define CB_STEP_NOTEST                                \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+__device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_plus_head,
+                                         uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
+                                         uint32_t q1_lds, unsigned long long &alive,
+                                         uint32_t &lane_steps) {
+  static_assert(kQ0Cap == 128 && kQ1Cap == 128, "ring masks and plane distances below");
+  unsigned long long save;
+  uint32_t cnt, tmp, ctr, slot;
+  double cr, ci, r, i, a;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "v_and_b32 %[slot], 0x7f, %[lph]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q0]\n\t"
+      "ds_read_b64 %[cr], %[slot]\n\t"
+      "ds_read_b64 %[ci], %[slot] offset:1024\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      // iterations 0..3 again, from z = c (first product: I*I with I = ci)
+      "v_mul_f64 %[a], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
+      "v_fma_f64 %[i], %[cr], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+      CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "1:\n\t"
+      CB_STEP_LIT
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_mov_b64 %[alive], exec\n\t"
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
+      "v_add_u32 %[slot], %[tail], %[slot]\n\t"
+      "v_and_b32 %[slot], 0x7f, %[slot]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
+      "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"
+      "ds_write2st64_b64 %[slot], %[r], %[i] offset0:4 offset1:6\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [alive] "=&s"(alive), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr),
+        [slot] "=&v"(slot), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i)
+      : [take] "s"(take), [lph] "v"(lane_plus_head), [q0] "s"(q0_lds), [n] "s"(n_steps),
+        [tail] "v"(q1_tail), [q1] "s"(q1_lds)
+      : "vcc", "scc", "memory");
+  lane_steps = cnt;
+}
+
 // ---- two orbits per lane, EXEC untouched (LONG) ----------------------------------------------------
 //
 // The LONG stage keeps TWO independent orbits (A and B) per lane and interleaves them instruction by
@@ -632,9 +695,14 @@ draw_wave_kernel(DrawArgs a) {
   // generator words have a single user and stay in place)
   constexpr bool fast_head = kFastHead;
   uint32_t rot = 0;  // rotation of the generator words, see head_draw
-  // LDS byte address of this wave's Q0 ring (the low half of a flat LDS address is the LDS offset)
+  // LDS byte addresses of this wave's Q0 / Q1 rings (the low half of a flat LDS address is the LDS offset)
   const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
+  const uint32_t q1_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q1_cr[0])));
+  // MID as one asm block (mid_pass) under the usual split: HEAD did four iterations, every escape inside
+  // MID is too fast (the stage ends at or before min_iter) and survivors have iterations left
+  const bool fast_mid = kFastHead && (min_iter >= long_start) && (long_steps > 0);
   // LONG lane state: two orbits per lane (see CB_STEP2)
   Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
@@ -839,6 +907,21 @@ draw_wave_kernel(DrawArgs a) {
     if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       const int n = q0_count < 64 ? q0_count : 64;
+      if (fast_mid) {  // the usual split: MID ends at or before min_iter and LONG follows
+        const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+        unsigned long long alive;
+        uint32_t steps;
+        mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) mid_steps,
+                 (uint32_t) (q1_head + q1_count), q1_lds, alive, steps);
+        q0_head = (q0_head + n) & (kQ0Cap - 1);
+        q0_count -= n;
+        n_iterate += steps;
+        n_too_fast += (unsigned long long) __popcll(take & ~alive);  // escaped before min_iter
+        q1_count += __popcll(alive);
+        if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
+        continue;
+      }
       const bool mine = lane_id() < n;
       Orbit o = {0, 0, 0, 0};
       if (mine) {
