@@ -154,26 +154,50 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, first, threads, states.data_ptr(), stream)
     samples_per_thread = SAMPLES_PER_PASS * PASSES_PER_STEP
-    # scratch for the deferred tile-binned scatter (pixel stream + its sorted copy), ~12 GiB of 288
+    # scratch for the deferred tile-binned scatter (pixel stream + its sorted copy), ~12 GiB of 288 each.
+    # Two of them and two streams, exactly as cb_renderer (capi.hip) drives the path: the scatter of
+    # launch k is issued on its own stream behind draw k, and draw k+1 starts at once on the other
+    # workspace, so that the scatter's first kernels fill the CUs the draw kernel's tail leaves idle.
     ws_bytes = 0 if args.direct_atomics else cb.scatter_workspace_bytes(dims, threads, samples_per_thread)
-    workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    workspaces = [torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
+    flush_stream_t = torch.cuda.Stream(device=dev)
+    draw_stream_t = torch.cuda.current_stream()
+    flush_stream = flush_stream_t.cuda_stream
+    draw_done = [torch.cuda.Event() for _ in range(2)]
+    flush_done = [torch.cuda.Event() for _ in range(2)]
+    flush_pending = [False, False]
+    turn = [0]
 
     # orbits still in flight at the end of a launch are carried to the next one instead of being
     # drained at a fraction of the lanes; the drain launch below, INSIDE the timed region, completes them
     carry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
 
-    def draw(samples=samples_per_thread):   # the dominant kernel: sample -> iterate -> replay (cudabrot.cu:379-414)
+    def step(samples=samples_per_thread, ev_draw=None, ev_flush=None):
+        """One launch of the dominant kernel (sample -> iterate -> replay, cudabrot.cu:379-414) on the draw
+        stream and its scatter on the flush stream."""
+        k = turn[0]
+        if flush_pending[k]:
+            draw_stream_t.wait_event(flush_done[k])     # workspace k is free once its last scatter is done
+            flush_pending[k] = False
+        if ev_draw:
+            ev_draw[0].record(draw_stream_t)
         cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples,
                            counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
-                           workspace.data_ptr() if ws_bytes else 0, ws_bytes, carry.data_ptr())
-
-    def flush():    # partition the deferred pixel stream by tile and add it to the histogram
+                           workspaces[k].data_ptr() if ws_bytes else 0, ws_bytes, carry.data_ptr())
+        if ev_draw:
+            ev_draw[1].record(draw_stream_t)
         if ws_bytes:
-            cb.flush_scatter(dims, hist.data_ptr(), threads, workspace.data_ptr(), ws_bytes, stream)
-
-    def step():
-        draw()
-        flush()
+            draw_done[k].record(draw_stream_t)
+            flush_stream_t.wait_event(draw_done[k])
+            if ev_flush:
+                ev_flush[0].record(flush_stream_t)
+            # partition the deferred pixel stream by tile and add it to the histogram
+            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[k].data_ptr(), ws_bytes, flush_stream)
+            if ev_flush:
+                ev_flush[1].record(flush_stream_t)
+            flush_done[k].record(flush_stream_t)
+            flush_pending[k] = True
+            turn[0] = k ^ 1
 
     def fence():
         torch.cuda.synchronize()
@@ -183,30 +207,52 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    draw(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
-    flush()
+    step(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
     fence()
     counters.zero_()
     torch.cuda.synchronize()
-    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
     dev_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     fence()
     t0 = time.perf_counter()
-    for a, b, c in ev:
-        a.record()
-        draw()
-        b.record()
-        flush()
-        c.record()
-    dev_ev[0].record()
-    draw(0)      # drain: every sample drawn in the K steps is complete before the clock stops
-    flush()
-    dev_ev[1].record()
+    for a, b, c, d in ev:
+        step(ev_draw=(a, b), ev_flush=(c, d))
+    dev_ev[0].record(draw_stream_t)
+    step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
+    dev_ev[1].record(draw_stream_t)
+    torch.cuda.synchronize()
     drain_ms = dev_ev[0].elapsed_time(dev_ev[1])
-    kernel_ms = [a.elapsed_time(b) for a, b, _ in ev]   # HIP events on the launch stream: the draw kernel
-    flush_ms = [b.elapsed_time(c) for _, b, c in ev]    # ... and the scatter kernels behind it
+    kernel_ms = [a.elapsed_time(b) for a, b, _, _ in ev]   # HIP events on the draw stream: the draw kernel
+    flush_ms = [c.elapsed_time(d) for _, _, c, d in ev] if ws_bytes else [0.0]  # ... on the flush stream: the scatter kernels
+
+    # The scatter kernels alone, for roofline_scatter: in the pipeline above they share the GPU with the
+    # next draw launch, so their event-to-event time there includes waiting for CUs.  Two more launches,
+    # outside the clock and not counted in `value`, with the scatter issued behind the draw kernel on the
+    # same stream.
+    counters_timed = counters.clone()
+    seq_flush_ms, seq_incr = [], []
+    if ws_bytes:
+        for _ in range(2):
+            before = int(counters.cpu().numpy().view(np.uint64)[7])
+            cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
+                               counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
+                               workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+            c1.record()
+            torch.cuda.synchronize()
+            seq_flush_ms.append(c0.elapsed_time(c1))
+            seq_incr.append(int(counters.cpu().numpy().view(np.uint64)[7]) - before)
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, 0, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
+        cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+    extra_samples = int(counters.cpu().numpy().view(np.uint64)[0]) - int(counters_timed.cpu().numpy().view(np.uint64)[0])
+    counters.copy_(counters_timed)   # the checks and per-launch figures below are about the timed region
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -228,7 +274,8 @@ def main():
         assert cnt["status"] == 0, "kernel reported an internal invariant violation"
         total_incr = int(hist.sum().item())
         warm = args.warmup * threads * samples_per_thread  # histogram also holds the warm-up launches
-        assert total_incr >= cnt["increments"] and (warm > 0 or total_incr == cnt["increments"])
+        # (it also holds the scatter-timing launches after the clock, extra_samples)
+        assert total_incr >= cnt["increments"] and (warm > 0 or extra_samples > 0 or total_incr == cnt["increments"])
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         avg_flush_ms = sum(flush_ms) / len(flush_ms)
         # EXECUTED iterations: the reference's count minus what the exact-periodicity check retired early
@@ -236,8 +283,12 @@ def main():
         incr_per_launch = loc["increments"] / args.steps
         traffic = recorded_traffic(threads * samples_per_thread)
         tflops = iters_per_launch * FLOPS_PER_ITERATION / (avg_ms * 1e-3) / 1e12
-        scatter_ms = avg_flush_ms if ws_bytes else avg_ms   # direct atomics happen inside the draw kernel
-        scatter_gbps = incr_per_launch * BYTES_PER_INCREMENT / (scatter_ms * 1e-3) / 1e9
+        if ws_bytes:   # the scatter kernels alone (sequential leg after the clock)
+            scatter_ms = sum(seq_flush_ms) / len(seq_flush_ms)
+            scatter_incr = sum(seq_incr) / len(seq_incr)
+        else:          # direct atomics happen inside the draw kernel
+            scatter_ms, scatter_incr = avg_ms, incr_per_launch
+        scatter_gbps = scatter_incr * BYTES_PER_INCREMENT / (scatter_ms * 1e-3) / 1e9
         line = {
             "metric": "Msamples/sec",
             "value": round(samples / elapsed / 1e6, 3),
@@ -298,11 +349,14 @@ def main():
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": round(scatter_gbps / PEAK_HBM_GBPS, 5),
-                "algorithmic_bytes_per_launch": incr_per_launch * BYTES_PER_INCREMENT,
+                "algorithmic_bytes_per_launch": scatter_incr * BYTES_PER_INCREMENT,
+                "pipelined_ms": round(avg_flush_ms, 4),
                 "traffic": traffic["scatter"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "note": "16 B per histogram increment (u64 read+write), increments counted in-kernel, over the time "
-                        "of the scatter kernels; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale)",
+                        "of the scatter kernels run alone (two launches after the clock); pipelined_ms is their "
+                        "event-to-event time inside the timed region, where they share the GPU with the next "
+                        "draw launch; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale)",
             },
         }
         if world == 1 and not args.no_full_iterate:
@@ -315,9 +369,10 @@ def main():
                 a.record()
                 cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
                                    counters.data_ptr(), cb.CB_KERNEL_FULL_ITERATE, stream,
-                                   workspace.data_ptr() if ws_bytes else 0, ws_bytes)
+                                   workspaces[0].data_ptr() if ws_bytes else 0, ws_bytes)
                 b.record()
-                flush()
+                if ws_bytes:
+                    cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
             torch.cuda.synchronize()
             fms = sum(a.elapsed_time(b) for a, b in fev) / len(fev)
             fc = dict(zip(cnt.keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))

@@ -39,6 +39,7 @@ struct BinLayout {
   uint32_t cap;         // entries per region (multiple of 4)
   uint32_t n_tiles;     // tiles_x * tiles_y
   uint32_t tiles_x;
+  uint32_t slice_entries;  // entries one accumulate workgroup takes
   uint32_t *wave_count;           // [n_waves]            entries written by each wave
   uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
   uint32_t *count;                // [n_tiles][n_waves]   counts, then exclusive prefix over waves

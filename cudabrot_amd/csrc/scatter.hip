@@ -19,6 +19,8 @@
 // Everything is a counting sort: no global atomics before the final flush, and the bytes written are
 // the same from run to run.  All of it is HBM-streaming work (4 + 4 + 4 + 2 + 2 = 16 bytes per
 // increment end to end, plus 16 KiB of flush per slice) that the draw kernel's fp64 loop leaves idle.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace cb {
@@ -28,7 +30,8 @@ namespace {
 constexpr uint32_t kScatterThreads = 512;
 constexpr uint32_t kChunkEntries = 8192;  // 16 per thread
 constexpr uint32_t kPerThread = kChunkEntries / kScatterThreads;
-constexpr uint32_t kSliceEntries = 65536;  // entries one accumulate workgroup takes
+constexpr uint32_t kSliceEntriesDefault = 262144;  // entries one accumulate workgroup takes: few enough
+                                                    // flushes of the 64 KiB tile, many enough slices to balance
 constexpr uint32_t kAccThreads = 512;
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(1024) bin_scan_tiles_kernel(BinLayout b) {
     const uint32_t t = threadIdx.x * kPer + k;
     v[k] = t < b.n_tiles ? b.tile_base[t] : 0ull;
     sum += v[k];
-    slices += (uint32_t) ((v[k] + kSliceEntries - 1u) / kSliceEntries);
+    slices += (uint32_t) ((v[k] + b.slice_entries - 1u) / b.slice_entries);
   }
   part[threadIdx.x] = sum;
   __syncthreads();
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(1024) bin_scan_tiles_kernel(BinLayout b) {
       b.slice_base[t] = srun;
     }
     run += v[k];
-    srun += (uint32_t) ((v[k] + kSliceEntries - 1u) / kSliceEntries);
+    srun += (uint32_t) ((v[k] + b.slice_entries - 1u) / b.slice_entries);
   }
   if (threadIdx.x == 1023) {
     b.tile_base[b.n_tiles] = part[1023];
@@ -176,17 +179,29 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
   }
   const uint32_t bins_per_thread = (b.n_tiles + kScatterThreads - 1u) / kScatterThreads;
 
+  // the chunk after the current one is loaded while the current one is ranked and sorted
+  uint32_t e_next[kPerThread];
+#pragma unroll
+  for (uint32_t k = 0; k < kPerThread; ++k) {
+    const uint32_t i = k * kScatterThreads + threadIdx.x;
+    e_next[k] = (i < n) ? src[i] : 0u;
+  }
   for (uint32_t base = 0; base < n; base += kChunkEntries) {
     const uint32_t m = (n - base) < kChunkEntries ? (n - base) : kChunkEntries;
     for (uint32_t t = threadIdx.x; t < b.n_tiles; t += kScatterThreads) cnt[t] = 0u;
-    __syncthreads();
     // 1. rank of every entry inside (chunk, tile)
     uint32_t e[kPerThread], r[kPerThread];
 #pragma unroll
-    for (uint32_t k = 0; k < kPerThread; ++k) {
-      const uint32_t i = k * kScatterThreads + threadIdx.x;
-      e[k] = (i < m) ? src[base + i] : 0u;
+    for (uint32_t k = 0; k < kPerThread; ++k) e[k] = e_next[k];
+    {
+      const uint32_t next = base + kChunkEntries;
+#pragma unroll
+      for (uint32_t k = 0; k < kPerThread; ++k) {
+        const uint32_t i = next + k * kScatterThreads + threadIdx.x;
+        e_next[k] = (i < n) ? src[i] : 0u;
+      }
     }
+    __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
@@ -251,8 +266,8 @@ __global__ void __launch_bounds__(kAccThreads) bin_accumulate_kernel(BinLayout b
   }
   const uint32_t t = lo;
   const unsigned long long tile_begin = b.tile_base[t], tile_end = b.tile_base[t + 1];
-  const unsigned long long begin = tile_begin + (unsigned long long) (s - b.slice_base[t]) * kSliceEntries;
-  const unsigned long long end = (begin + kSliceEntries < tile_end) ? begin + kSliceEntries : tile_end;
+  const unsigned long long begin = tile_begin + (unsigned long long) (s - b.slice_base[t]) * b.slice_entries;
+  const unsigned long long end = (begin + b.slice_entries < tile_end) ? begin + b.slice_entries : tile_end;
 
   for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) tile[p] = 0u;
   __syncthreads();
@@ -305,6 +320,11 @@ size_t bin_fixed_bytes(uint32_t n_waves, uint32_t n_tiles) {
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves) {
   BinLayout b;
   b.enabled = 0;
+  b.slice_entries = kSliceEntriesDefault;
+  if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob
+    const long v = atol(e);
+    if (v >= 4096 && v <= (1l << 30)) b.slice_entries = (uint32_t) v;
+  }
   b.n_waves = n_waves;
   b.cap = 0;
   b.n_tiles = 0;
@@ -366,7 +386,7 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   hipLaunchKernelGGL(bin_scatter_kernel, dim3(b.n_waves), dim3(kScatterThreads), scatter_lds, stream, b);
   // upper bound on the number of slices: one partial slice per tile + the full ones
   const unsigned long long max_entries = (unsigned long long) b.n_waves * b.cap;
-  const uint32_t slices = b.n_tiles + (uint32_t) (max_entries / kSliceEntries) + 1u;
+  const uint32_t slices = b.n_tiles + (uint32_t) (max_entries / b.slice_entries) + 1u;
   hipLaunchKernelGGL(bin_accumulate_kernel, dim3(slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
   return hipGetLastError();
 }
