@@ -232,14 +232,18 @@ def main():
     # outside the clock and not counted in `value`, with the scatter issued behind the draw kernel on the
     # same stream.
     counters_timed = counters.clone()
-    seq_flush_ms, seq_incr = [], []
+    seq_flush_ms, seq_incr, seq_draw_ms = [], [], []
     if ws_bytes:
         for _ in range(2):
             before = int(counters.cpu().numpy().view(np.uint64)[7])
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
             cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
                                counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
                                workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
+            d1.record()
             torch.cuda.synchronize()
+            seq_draw_ms.append(d0.elapsed_time(d1))
             c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             c0.record()
             cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
@@ -330,6 +334,9 @@ def main():
                 "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
                 "issue_frac": round(tflops / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(avg_ms, 4),
+                "alone_ms": round(sum(seq_draw_ms) / len(seq_draw_ms), 4) if seq_draw_ms else None,
+                "frac_alone": round(tflops * avg_ms / (sum(seq_draw_ms) / len(seq_draw_ms)) / PEAK_FP64_VECTOR_TFLOPS, 4)
+                if seq_draw_ms else None,
                 "algorithmic_flops_per_launch": iters_per_launch * FLOPS_PER_ITERATION,
                 "traffic": traffic["draw"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
@@ -337,7 +344,9 @@ def main():
                         "the kernel EXECUTED (counted in-kernel; orbits found exactly periodic are retired early "
                         "with the identical outcome, so at max_iter=20000 only ~14 % of the reference's iterations "
                         "are executed); the kernel also draws, tests and replays, so this is a lower bound on its "
-                        "fp64 use; the kernel executes an iteration as 6 fp64 instructions + 1 compare "
+                        "fp64 use; avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the "
+                        "previous launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, "
+                        "after the clock); the kernel executes an iteration as 6 fp64 instructions + 1 compare "
                         "(doubled-coordinate form of the 10-flop step), so the ceiling of `frac` is 10/14 = 0.714; "
                         "issue_frac = fp64 issue-slot utilisation (7 per iteration)",
             },

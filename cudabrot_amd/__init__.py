@@ -10,6 +10,7 @@ from .capi import (  # noqa: F401
     CB_DEFAULT_RNG_SEED,
     CB_DEFAULT_THREADS,
     CB_KERNEL_DEFAULT,
+    CB_KERNEL_FLAG_BURNING_SHIP,
     CB_KERNEL_FULL_ITERATE,
     CB_KERNEL_SIMPLE,
     CB_KERNEL_TIMED,
@@ -42,6 +43,7 @@ __all__ = [
     "CB_DEFAULT_RNG_SEED",
     "CB_DEFAULT_THREADS",
     "CB_KERNEL_DEFAULT",
+    "CB_KERNEL_FLAG_BURNING_SHIP",
     "CB_KERNEL_FULL_ITERATE",
     "CB_KERNEL_SIMPLE",
     "CB_KERNEL_TIMED",

@@ -131,7 +131,7 @@ namespace {
 // Adds one launch (or, with passes == 0, the drain of the carried work) and its flush to the
 // renderer's streams.
 int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
-  const bool wave = kernel_variant != CB_KERNEL_SIMPLE;
+  const bool wave = (kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) != CB_KERNEL_SIMPLE;
   const bool deferred = r->d_workspace[0] && wave;
   const int k = r->next_workspace;
   if (deferred && r->flush_pending[k]) {
@@ -248,23 +248,25 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        void *d_workspace, size_t workspace_bytes, void *d_carry, void *stream) {
   if (!dims || !iterations || !d_hist || !d_states) return (int) hipErrorInvalidValue;
   if (dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
-  if (kernel_variant == CB_KERNEL_SIMPLE) {  // the baseline kernel: atomics, every launch complete
+  const bool ship = (kernel_variant & CB_KERNEL_FLAG_BURNING_SHIP) != 0;
+  const int base_variant = kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP;
+  if (base_variant == CB_KERNEL_SIMPLE) {  // the baseline kernel: atomics, every launch complete
     d_workspace = nullptr;
     d_carry = nullptr;
   }
-  const cb::DrawArgs a = make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread,
-                                   d_counters, d_workspace, workspace_bytes, d_carry);
+  cb::DrawArgs a = make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread,
+                             d_counters, d_workspace, workspace_bytes, d_carry);
+  a.burning_ship = ship ? 1 : 0;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  switch (kernel_variant) {
+  const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
+  switch (base_variant) {
     case CB_KERNEL_DEFAULT:
-      return (int) cb::launch_draw_wave(a, false, s);
-    case CB_KERNEL_FULL_ITERATE: {
-      cb::DrawArgs full = a;
-      full.check_periodic = 0;
-      return (int) cb::launch_draw_wave(full, false, s);
-    }
+      return (int) wave(a, false, s);
+    case CB_KERNEL_FULL_ITERATE:
+      a.check_periodic = 0;
+      return (int) wave(a, false, s);
     case CB_KERNEL_TIMED:
-      return (int) cb::launch_draw_wave(a, true, s);
+      return (int) wave(a, true, s);
     case CB_KERNEL_SIMPLE:
       return (int) cb::launch_draw_simple(a, s);
     default:
@@ -331,13 +333,14 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
     const long v = e ? atol(e) : 0;
     return (v >= 1 && v <= 4096) ? (uint32_t) v : kRendererPassesPerLaunch;
   }();
-  if (kernel_variant == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") && !g_wave_dump) {
+  if ((kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") &&
+      !g_wave_dump) {
     const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
     if (hipMalloc(&g_wave_dump, bytes) != hipSuccess || hipMemset(g_wave_dump, 0, bytes) != hipSuccess) {
       g_wave_dump = nullptr;
     }
   }
-  if (!r->workspace_tried && kernel_variant != CB_KERNEL_SIMPLE &&
+  if (!r->workspace_tried && (kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) != CB_KERNEL_SIMPLE &&
       getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
     // scatter workspace for the largest launch this call makes; on any failure: direct atomics
     r->workspace_tried = 1;

@@ -12,7 +12,7 @@
 //  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
 //    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
 //  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
-//    --stats.
+//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship.
 #include <errno.h>
 #include <signal.h>
 #include <stdint.h>
@@ -42,6 +42,7 @@ struct Settings {
   long fixed_passes = -1;                           // --passes (extension; <0: run by the clock)
   int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
   bool print_stats = false;                         // --stats  (extension)
+  bool burning_ship = false;                        // --burning-ship (extension; cudabrot.cu:15-17)
   uint64_t seed = CB_DEFAULT_RNG_SEED;              // --seed (extension; cudabrot.cu:37)
   const char *rng_state_file = nullptr;             // --rng-state (extension): true-resume sidecar
   int tone_mode = CB_TONE_AUTO;                     // --tonemap (extension): device table / thresholds
@@ -155,6 +156,8 @@ const std::vector<Flag> &flag_table() {
        }},
       {"--stats", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.print_stats = true; }},
+      {"--burning-ship", Value::kNone, nullptr, false,
+       [](Settings &s, long, double, const char *) { s.burning_ship = true; }},
       {"--seed", Value::kInt, nullptr, false,
        [](Settings &s, long i, double, const char *) { s.seed = (uint64_t) i; }},
       {"--rng-state", Value::kText, nullptr, false,
@@ -477,7 +480,9 @@ class Run {
         next = cfg_.fixed_passes - done;
         if (next > 256) next = 256;
       }
-      CB_CHECK(cb_renderer_render_passes(renderer_, (uint32_t) next, cfg_.kernel_variant));
+      CB_CHECK(cb_renderer_render_passes(
+          renderer_, (uint32_t) next,
+          cfg_.kernel_variant | (cfg_.burning_ship ? CB_KERNEL_FLAG_BURNING_SHIP : 0)));
       done += next;
       if (!by_clock) continue;
       const double elapsed = wall_seconds() - t0;

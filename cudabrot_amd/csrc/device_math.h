@@ -122,6 +122,28 @@ __device__ __forceinline__ double mandel_step2(double CR, double CI, double &R, 
   return __builtin_fma(NI, NI, NR * NR);
 }
 
+// RENDER_BURNING_SHIP (cudabrot.cu:15-17,327-330,353-356): real and imag are replaced by their
+// magnitudes before the step.  The squares do not notice; the cross term becomes 2|r||i|, which hipcc
+// (gfx950) forms as fma(|i|, |r|+|r|, ci).
+__device__ __forceinline__ double mandel_step_ship(double cr, double ci, double &r, double &i) {
+  const double ii = i * i;
+  const double t = __builtin_fma(r, r, -ii);
+  const double nr = cr + t;
+  const double ni = __builtin_fma(__builtin_fabs(r) + __builtin_fabs(r), __builtin_fabs(i), ci);
+  r = nr;
+  i = ni;
+  return __builtin_fma(ni, ni, nr * nr);
+}
+__device__ __forceinline__ double mandel_step2_ship(double CR, double CI, double &R, double &I) {
+  const double II = I * I;
+  const double T = __builtin_fma(R, R, -II);
+  const double NI = __builtin_fma(__builtin_fabs(R), __builtin_fabs(I), CI);
+  const double NR = __builtin_fma(T, 0.5, CR);
+  R = NR;
+  I = NI;
+  return __builtin_fma(NI, NI, NR * NR);
+}
+
 // Canvas geometry as the kernels consume it: FractalDimensions (cudabrot.cu:46-58) plus the exact
 // reciprocal fast path of SURVEY.md H3.
 struct Canvas {

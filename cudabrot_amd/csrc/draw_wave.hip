@@ -43,6 +43,21 @@
 
 #include "draw_common.h"
 
+// This file is compiled twice: as is, and with -DCB_BURNING_SHIP for the reference's
+// RENDER_BURNING_SHIP variant (cudabrot.cu:15-17): real and imag are replaced by their magnitudes
+// before each step (:327-330, :353-356), which only the cross term 2*real*imag notices -- a pair of
+// |.| operand modifiers on one instruction of the step, free of charge -- and the cardioid / bulb
+// shortcut is skipped (:397-399).  The second build exports launch_draw_wave_ship.
+#ifdef CB_BURNING_SHIP
+#define CB_AL "|"
+#define CB_AR "|"
+#define CB_LAUNCH_NAME launch_draw_wave_ship
+#else
+#define CB_AL ""
+#define CB_AR ""
+#define CB_LAUNCH_NAME launch_draw_wave
+#endif
+
 namespace cb {
 
 namespace {
@@ -94,7 +109,7 @@ __device__ __forceinline__ double uniform_f64(double v) {
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
   "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
-  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
@@ -318,7 +333,7 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
   "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
-  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
@@ -334,6 +349,10 @@ __device__ __forceinline__ void head_test(unsigned long long valid, double cr, d
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b64 exec, %[valid]\n\t"
+#ifdef CB_BURNING_SHIP
+      "v_mul_f64 %[a], %[ci], %[ci]\n\t"             // II; no shortcut in this variant (cudabrot.cu:397-399)
+      "s_mov_b64 %[alive0], exec\n\t"
+#else
       "v_mul_f64 %[a], %[ci], %[ci]\n\t"             // II
       "v_add_f64 %[x], %[cr], -0.5\n\t"              // X = 2 (re - 1/4)
       "v_add_f64 %[r], %[cr], 2.0\n\t"               // T = 2 (re + 1)
@@ -345,11 +364,12 @@ __device__ __forceinline__ void head_test(unsigned long long valid, double cr, d
       "s_mov_b64 %[alive0], vcc\n\t"
       "v_cmp_nlt_f64_e64 %[alive4], %[q], %[a]\n\t"  // !(Q*S < II)
       "s_and_b64 %[alive0], %[alive0], %[alive4]\n\t"
+#endif
       "s_mov_b64 exec, %[alive0]\n\t"
       "s_bcnt1_i32_b64 %[cnt], %[alive0]\n\t"
       // step 1 from z = c; its first product I*I is II
       "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
-      "v_fma_f64 %[i], %[cr], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
       "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
       "v_mul_f64 %[a], %[r], %[r]\n\t"
       "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
@@ -383,7 +403,7 @@ __device__ __forceinline__ void head_test(unsigned long long valid, double cr, d
 #define CB_STEP_NOTEST                                \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
-  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
 __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_plus_head,
                                          uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
@@ -406,7 +426,7 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       // iterations 0..3 again, from z = c (first product: I*I with I = ci)
       "v_mul_f64 %[a], %[ci], %[ci]\n\t"
       "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
-      "v_fma_f64 %[i], %[cr], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
       "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
       CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
       "s_cmp_eq_u32 %[n], 0\n\t"
@@ -459,9 +479,9 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
   "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
   "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
   "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
-  "v_fma_f64 %[ia], %[ra], %[ia], %[cia]\n\t"             \
+  "v_fma_f64 %[ia], " CB_AL "%[ra]" CB_AR ", " CB_AL "%[ia]" CB_AR ", %[cia]\n\t"             \
   "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
-  "v_fma_f64 %[ib], %[rb], %[ib], %[cib]\n\t"             \
+  "v_fma_f64 %[ib], " CB_AL "%[rb]" CB_AR ", " CB_AL "%[ib]" CB_AR ", %[cib]\n\t"             \
   "s_add_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
   "v_fma_f64 %[ra], %[a0], 0.5, %[cra]\n\t"               \
   "s_add_u32 %[cnt], %[cnt], %[t1]\n\t"                   \
@@ -553,7 +573,7 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
   "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
-  "v_fma_f64 %[i], %[r], %[i], %[ci]\n\t"                 \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"                 \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_add_u32 %[ps], 1, %[ps]\n\t"                         \
   "v_cmp_le_f64_e64 %[hy], %[miny2], %[i]\n\t"            \
@@ -812,7 +832,11 @@ draw_wave_kernel(DrawArgs a) {
           bool done = false, hit = false;
           int row = 0, col = 0;
           if (p_act) {
+#ifdef CB_BURNING_SHIP
+            const double m4 = mandel_step2_ship(po.cr, po.ci, po.r, po.i);  // cudabrot.cu:353-359
+#else
             const double m4 = mandel_step2(po.cr, po.ci, po.r, po.i);  // cudabrot.cu:357-359
+#endif
             hit = pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);      // cudabrot.cu:308-311 (halving is exact)
             if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);         // cudabrot.cu:312
             p_steps++;
@@ -869,7 +893,11 @@ draw_wave_kernel(DrawArgs a) {
       if (valid) {
         o.cr = sample_coordinate2(rng);  // cudabrot.cu:392 (doubled, like everything below)
         o.ci = sample_coordinate2(rng);  // cudabrot.cu:393
+#ifdef CB_BURNING_SHIP
+        alive = true;  // cudabrot.cu:397-399: no shortcut in this variant
+#else
         alive = !(in_main_cardioid2(o.cr, o.ci) || in_order2_bulb2(o.cr, o.ci));  // cudabrot.cu:398
+#endif
       }
       o.r = o.cr;
       o.i = o.ci;
@@ -1177,7 +1205,7 @@ draw_wave_kernel(DrawArgs a) {
 
 }  // namespace
 
-hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
+hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   const bool drain_launch = a.carry != nullptr && a.drain != 0;
   if (a.n_threads == 0 || (a.samples_per_thread == 0 && !drain_launch)) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
@@ -1206,6 +1234,7 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream) {
   return hipGetLastError();
 }
 
+#ifndef CB_BURNING_SHIP
 // Stage split.  HEAD does iterations [0, head), MID [head, head + mid), LONG the rest in chunks of
 // kChunk.  mid is chosen so that min_iter - (head + mid) is a multiple of kChunk whenever min_iter
 // lies beyond the MID stage: then no LONG chunk straddles min_iter.
@@ -1226,5 +1255,7 @@ void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps) {
   *head_steps = head;
   *mid_steps = mid;
 }
+
+#endif
 
 }  // namespace cb

@@ -86,6 +86,9 @@ struct DrawArgs {
   // words per wave, zeroed by the caller before the first launch.
   unsigned long long *carry;
   int drain;
+  // the reference's RENDER_BURNING_SHIP variant (cudabrot.cu:15-17); read by draw_simple_kernel, the
+  // wave kernel has a build of its own for it (launch_draw_wave_ship)
+  int burning_ship;
 };
 
 constexpr uint32_t kCarryHeaderWords = 8;
@@ -102,6 +105,7 @@ hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n
                            uint32_t *d_states, const uint32_t *d_matrices, hipStream_t stream);
 hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream);
 hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
+hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stream);
 
 // Steps per chunk of the LONG stage; the stage split is chosen so that no chunk straddles min_iter.
 constexpr int kChunk = 32;

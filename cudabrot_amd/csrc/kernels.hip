@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) draw_simple_kernel(DrawArgs a) {
       const double real = sample_coordinate(rng);
       const double imag = sample_coordinate(rng);
       st.samples++;
-      if (in_main_cardioid(real, imag) || in_order2_bulb(real, imag)) {  // cudabrot.cu:398
+      if (!a.burning_ship && (in_main_cardioid(real, imag) || in_order2_bulb(real, imag))) {  // cudabrot.cu:397-399
         st.rejected++;
         continue;
       }
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) draw_simple_kernel(DrawArgs a) {
       double r = real, i = imag;
       int k = a.max_iter;
       for (int it = 0; it < a.max_iter; ++it) {
-        if (mandel_step(real, imag, r, i) > 4.0) {
+        if ((a.burning_ship ? mandel_step_ship(real, imag, r, i) : mandel_step(real, imag, r, i)) > 4.0) {
           k = it;
           break;
         }
@@ -156,7 +156,7 @@ __global__ void __launch_bounds__(256) draw_simple_kernel(DrawArgs a) {
       r = real;
       i = imag;
       for (int it = 0; it <= a.max_iter; ++it) {
-        const double m = mandel_step(real, imag, r, i);
+        const double m = a.burning_ship ? mandel_step_ship(real, imag, r, i) : mandel_step(real, imag, r, i);
         st.replay_steps++;
         st.increments += increment_pixel_counter(r, i, a.hist, cv) ? 1ull : 0ull;
         if (m > 4.0) break;

@@ -86,6 +86,10 @@ typedef struct {
                                     sample is iterated to max_iter as the reference does (same result;
                                     for measuring the iterate loop against the fp64 roofline)        */
 
+/* OR-ed into a kernel variant: the reference's RENDER_BURNING_SHIP build (cudabrot.cu:15-17 -- there a
+ * compile-time switch): |real|, |imag| before every step and no cardioid / bulb shortcut. */
+#define CB_KERNEL_FLAG_BURNING_SHIP 0x100
+
 /* RecomputePixelDeltas (cudabrot.cu:505-527).  Returns 1 and fills delta_* if the canvas is valid,
  * else 0 and, if msg is not NULL, *msg points at the reference's message for the failed check. */
 int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg);

@@ -109,9 +109,10 @@ def first_sample(seed, subsequence):
 
 
 def render(w, h, max_iter, min_iter, n_threads, passes, box=(-2.0, 2.0, -2.0, 2.0), first_subsequence=0,
-           seed=1337, samples_per_thread=50, omp_threads=None, hist=None, states=None):
+           seed=1337, samples_per_thread=50, omp_threads=None, hist=None, states=None, burning_ship=False):
     """`passes` launches of DrawBuddhabrot over n_threads threads -> (u64 hist [h,w], counters dict).
 
+    burning_ship: the reference's RENDER_BURNING_SHIP build (cudabrot.cu:15-17).
     box = (min_real, max_real, min_imag, max_imag).  omp_threads=None: sequential (the reference's
     race-free semantics); otherwise the OpenMP variant with that many workers (0 = all).
     """
@@ -121,13 +122,17 @@ def render(w, h, max_iter, min_iter, n_threads, passes, box=(-2.0, 2.0, -2.0, 2.
     if hist is None:
         hist = np.zeros((h, w), dtype=np.uint64)
     cnt = Counters()
-    for _ in range(passes):
-        if omp_threads is None:
-            lib.orc_draw_buddhabrot(C.byref(d), hist.ctypes.data, C.byref(it), st.ctypes.data, n_threads,
-                                    samples_per_thread, C.byref(cnt))
-        else:
-            lib.orc_draw_buddhabrot_omp(C.byref(d), hist.ctypes.data, C.byref(it), st.ctypes.data, n_threads,
-                                        samples_per_thread, C.byref(cnt), omp_threads)
+    lib.orc_set_burning_ship(1 if burning_ship else 0)
+    try:
+        for _ in range(passes):
+            if omp_threads is None:
+                lib.orc_draw_buddhabrot(C.byref(d), hist.ctypes.data, C.byref(it), st.ctypes.data, n_threads,
+                                        samples_per_thread, C.byref(cnt))
+            else:
+                lib.orc_draw_buddhabrot_omp(C.byref(d), hist.ctypes.data, C.byref(it), st.ctypes.data, n_threads,
+                                            samples_per_thread, C.byref(cnt), omp_threads)
+    finally:
+        lib.orc_set_burning_ship(0)
     return hist, cnt.as_dict()
 
 

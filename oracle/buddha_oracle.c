@@ -182,12 +182,22 @@ int orc_in_order2_bulb(double real, double imag) {
   return __builtin_fma(tmp, tmp, imag_squared) < (1.0 / 16.0);
 }
 
+/* RENDER_BURNING_SHIP (cudabrot.cu:15-17): a compile-time switch in the reference, a run-time one
+ * here.  With it, real and imag are replaced by their magnitudes before each step (:327-330,
+ * :353-356) -- only the cross term notices -- and the cardioid / bulb shortcut is skipped (:397-399). */
+static int g_burning_ship = 0;
+void orc_set_burning_ship(int on) { g_burning_ship = on ? 1 : 0; }
+int orc_get_burning_ship(void) { return g_burning_ship; }
+
 /* One z <- z^2 + c step, cudabrot.cu:331-333 (= :357-359); returns |z|^2 as of :336 (= :363). */
 static inline double mandel_step(double cr, double ci, double *r, double *i) {
   const double ii = (*i) * (*i);
   const double t = __builtin_fma(*r, *r, -ii);
   const double nr = cr + t;
-  const double ni = __builtin_fma((*r) + (*r), *i, ci);
+  /* ship: hipcc (gfx950) and x86 clang both form |r|+|r| and fuse its product with |i| */
+  const double ni = g_burning_ship
+                        ? __builtin_fma(__builtin_fabs(*r) + __builtin_fabs(*r), __builtin_fabs(*i), ci)
+                        : __builtin_fma((*r) + (*r), *i, ci);
   *r = nr;
   *i = ni;
   return __builtin_fma(ni, ni, nr * nr);
@@ -242,7 +252,7 @@ static void draw_thread(const orc_dims *dims, uint64_t *hist, const orc_iters *i
     const double real = (orc_uniform_double(rng) * 4.0) - 2.0;
     const double imag = (orc_uniform_double(rng) * 4.0) - 2.0;
     c->samples++;
-    if (orc_in_main_cardioid(real, imag) || orc_in_order2_bulb(real, imag)) {
+    if (!g_burning_ship && (orc_in_main_cardioid(real, imag) || orc_in_order2_bulb(real, imag))) {
       c->rejected++;
       continue;
     }

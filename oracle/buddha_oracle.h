@@ -75,6 +75,9 @@ int orc_in_main_cardioid(double real, double imag);
 int orc_in_order2_bulb(double real, double imag);
 /* cudabrot.cu:319-340 */
 int orc_iterate_mandelbrot(double start_real, double start_imag, int max_iterations);
+/* RENDER_BURNING_SHIP (cudabrot.cu:15-17) as a run-time switch of this library (process-wide). */
+void orc_set_burning_ship(int on);
+int orc_get_burning_ship(void);
 
 /*
  * DrawBuddhabrot (cudabrot.cu:379-414) for "threads" [0,n_threads), executed one after another

@@ -91,6 +91,15 @@ def test_rng_state_sidecar_continues_the_sample_stream(exe, oracle, tmp_path):
     assert r3.returncode == 1 and "is not a generator state for seed 99" in r3.stdout
 
 
+def test_burning_ship_flag(exe, oracle, tmp_path):
+    """--burning-ship (extension): the reference's RENDER_BURNING_SHIP build (cudabrot.cu:15-17)."""
+    buf = str(tmp_path / "ship.bin")
+    r = run(exe, "--passes", "1", "--burning-ship", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 0
+    hist, _ = oracle.render(300, 200, 200, 20, T, 1, burning_ship=True, omp_threads=0)
+    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+
+
 def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path):
     buf = str(tmp_path / "seed.bin")
     r = run(exe, "--passes", "1", "--seed", "4242", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)

@@ -331,3 +331,24 @@ def test_rng_states_round_trip_makes_a_true_resume(cb, oracle):
     assert np.array_equal(resumed, three)
     with pytest.raises(ValueError):
         cb.Renderer(dims, it, n_threads=t).write_rng_states(states[:-1])
+
+
+@pytest.mark.parametrize("variant_name", ["CB_KERNEL_DEFAULT", "CB_KERNEL_SIMPLE", "CB_KERNEL_FULL_ITERATE"])
+def test_burning_ship_variant_matches_the_reference_build_with_the_define(cb, oracle, variant_name):
+    """RENDER_BURNING_SHIP (cudabrot.cu:15-17): |real|, |imag| before every step, no cardioid / bulb
+    shortcut.  CB_KERNEL_FLAG_BURNING_SHIP selects it at run time; the oracle's switch is pinned against the
+    reference's lines compiled with the define (test_oracle_vs_ref.py)."""
+    w, h, t, passes = 192, 160, 4096, 2
+    dims = cb.FractalDimensions.make(w, h, -2.0, 2.0, -2.0, 1.0)
+    variant = getattr(cb, variant_name) | cb.CB_KERNEL_FLAG_BURNING_SHIP
+    with cb.Renderer(dims, cb.IterationControl(600, 20), n_threads=t) as r:
+        r.render_passes(passes, variant)
+        got = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    ref, rc = oracle.render(w, h, 600, 20, t, passes, (-2.0, 2.0, -2.0, 1.0), burning_ship=True)
+    assert np.array_equal(got, ref)
+    assert cnt["status"] == 0 and cnt["rejected"] == 0 == rc["rejected"]
+    for k in ("samples", "never_escaped", "too_fast", "recorded", "increments", "replay_steps"):
+        assert cnt[k] == rc[k], k
+    plain, _ = oracle.render(w, h, 600, 20, t, passes, (-2.0, 2.0, -2.0, 1.0))
+    assert not np.array_equal(got, plain)

@@ -52,6 +52,27 @@ def test_histogram_equals_reference_lines(oracle, ref, cfg):
     assert np.array_equal(mine, theirs)
 
 
+SHIP_CONFIGS = [
+    (256, 256, 100, 20, 20000, 1, (-2.0, 2.0, -2.0, 2.0), 0),
+    (400, 300, 2000, 20, 8000, 2, (-2.0, 2.0, -2.0, 1.0), 0),
+    (333, 77, 500, 0, 3000, 2, (-1.9, 0.9, -1.3, 0.4), 4096),
+]
+
+
+@pytest.mark.parametrize("cfg", SHIP_CONFIGS, ids=lambda c: "%dx%d_m%d_c%d" % c[:4])
+def test_burning_ship_histogram_equals_reference_lines(oracle, cfg):
+    """RENDER_BURNING_SHIP (cudabrot.cu:15-17,327-330,353-356,397-399): the oracle's run-time switch
+    against the reference's lines compiled with the define."""
+    ship = oracle.ref_library("ship_fma")
+    if ship is None:
+        pytest.skip("oracle/_ref/libref_ship_fma.so not built")
+    w, h, m, c, t, p, box, first = cfg
+    got, _ = oracle.render(w, h, m, c, t, p, box, first_subsequence=first, burning_ship=True)
+    assert np.array_equal(got, ref_render(ship, w, h, m, c, t, p, box, first))
+    plain, _ = oracle.render(w, h, m, c, t, p, box, first_subsequence=first)
+    assert not np.array_equal(got, plain)          # and the switch is off again afterwards
+
+
 def test_rng_stream_equals_rocrand(oracle, ref):
     for s in (0, 1, 2, 63, 64, 19999, 262143, 262144, 2097151, (1 << 33) + 5):
         out = (C.c_uint32 * 64)()
