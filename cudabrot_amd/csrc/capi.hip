@@ -230,16 +230,10 @@ size_t cb_carry_bytes(uint32_t n_threads) {
 
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
                                   uint32_t samples_per_thread) {
-  if (!dims || dims->w <= 0 || dims->h <= 0 || dims->w > 65536 || dims->h > 65536) return 0;
-  const unsigned long long tiles = (unsigned long long) ((dims->w + cb::kTileSize - 1) / cb::kTileSize) *
-                                   (unsigned long long) ((dims->h + cb::kTileSize - 1) / cb::kTileSize);
-  if (tiles > cb::kMaxTiles || n_threads == 0 || samples_per_thread == 0) return 0;
+  if (!dims || dims->w <= 0 || dims->h <= 0 || n_threads == 0 || samples_per_thread == 0) return 0;
   const uint32_t n_waves = cb::draw_wave_count(n_threads);
   const double entries = (double) n_threads * (double) samples_per_thread * kEntriesPerSample;
-  double per_wave = entries / n_waves;
-  if (per_wave < 2.0 * cb::kMinRegionEntries) per_wave = 2.0 * cb::kMinRegionEntries;
-  return cb::bin_fixed_bytes(n_waves, (uint32_t) tiles) +
-         (size_t) (per_wave * n_waves) * cb::kBinBytesPerEntry + 4096;
+  return cb::bin_workspace_bytes(dims->w, dims->h, n_waves, entries / n_waves);
 }
 
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,

@@ -30,29 +30,44 @@ void seed_state(uint64_t seed, uint32_t x[5], uint32_t *d);
 constexpr int kTileShift = 7;
 constexpr int kTileSize = 1 << kTileShift;          // 128 x 128 pixels
 constexpr int kTilePixels = kTileSize * kTileSize;  // 16384 u32 counters = 64 KiB of LDS
-constexpr uint32_t kMaxTiles = 4096;                // canvases up to 8192 x 8192
+constexpr uint32_t kMaxTiles = 4096;                // one sorting level up to here (8192 x 8192 pixels)
 constexpr uint32_t kMinRegionEntries = 4096;        // below this per wave the workspace is not used
 
 struct BinLayout {
   uint32_t enabled;     // 0: REPLAY adds to the histogram directly
   uint32_t n_waves;     // regions in the stream (= waves of the draw kernel)
-  uint32_t cap;         // entries per region (multiple of 4)
+  uint32_t cap;         // entries per wave region (multiple of 4)
   uint32_t n_tiles;     // tiles_x * tiles_y
   uint32_t tiles_x;
   uint32_t slice_entries;  // entries one accumulate workgroup takes
+  // more than kMaxTiles tiles: the stream is first partitioned into groups of 1024 tiles (level A),
+  // then every fixed-size region of the grouped stream is sorted by tile (level B); scatter.hip
+  uint32_t two_level;
+  uint32_t n_groups;
+  uint32_t max_regions;   // size of the region table (level B; = n_waves with one level)
+  uint32_t count_stride;  // row length of `count`
   uint32_t *wave_count;           // [n_waves]            entries written by each wave
   uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
-  uint32_t *count;                // [n_tiles][n_waves]   counts, then exclusive prefix over waves
+  uint32_t *a_count;              // [n_groups*16][n_waves]  level A counts, then prefix over waves
+  unsigned long long *a_base;     // [n_groups*16 + 1]    level A exclusive prefix over keys
+  uint32_t *grouped;              // [n_waves * cap]      the stream, grouped (two levels)
+  unsigned long long *region_start;  // [max_regions]     regions of the (grouped) stream ...
+  uint32_t *region_count;         // [max_regions]
+  uint32_t *region_group;         // [max_regions]        ... their group
+  uint32_t *region_index;         // [max_regions]        ... and index inside the group
+  uint32_t *group_regions;        // [n_groups]           regions per group
+  uint32_t *n_regions;            // [1]
+  uint32_t *count;                // [n_tiles][count_stride]  counts, then exclusive prefix over regions
   unsigned long long *tile_base;  // [n_tiles + 1]        exclusive prefix over tiles
   uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate slices
   uint16_t *sorted;               // [n_waves * cap]      in-tile offsets grouped by tile
 };
 
-// Fixed (entry-independent) bytes of a workspace and bytes per stream entry.
-size_t bin_fixed_bytes(uint32_t n_waves, uint32_t n_tiles);
-constexpr size_t kBinBytesPerEntry = sizeof(uint32_t) + sizeof(uint16_t);
+// Bytes of a workspace for launches that write about entries_per_wave stream entries per wave (0 if
+// the canvas cannot use one: a side above 65536 or more than 65536 tiles).
+size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave);
 // Carves `bytes` at `workspace` into a BinLayout (enabled = 0 if it is too small or the canvas does
-// not qualify: more than kMaxTiles tiles or a side above 65536).
+// not qualify).
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves);
 // count -> scan -> scatter -> accumulate on `stream`, after the draw kernel that filled the stream.
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,

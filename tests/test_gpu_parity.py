@@ -278,6 +278,34 @@ def test_canvas_that_cannot_use_the_workspace(cb, oracle):
     assert_same(got, cpu)
 
 
+@pytest.mark.parametrize("shape", [(700, 500), (1300, 900)])
+def test_two_level_sort_on_a_small_canvas(cb, oracle, monkeypatch, shape):
+    """The two-level sort of scatter.hip (groups of 1024 tiles, then tiles) forced on canvases that one
+    level would handle: same histogram.  1300 x 900 has 88 tiles; 700 x 500 has 24 (one partial group)."""
+    monkeypatch.setenv("CUDABROT_AMD_TWO_LEVEL", "1")
+    w, h = shape
+    t, passes = 8192, 3
+    dims = cb.FractalDimensions.make(w, h)
+    size = cb.scatter_workspace_bytes(dims, t, 50)
+    assert size > 0
+    got = _torch_render(cb, w, h, 600, 20, t, passes, size)
+    cpu = oracle.render(w, h, 600, 20, t, passes)
+    assert_same(got, cpu)
+
+
+def test_canvas_beyond_4096_tiles_uses_two_levels(cb, oracle):
+    """9100 x 8300 pixels = 72 x 65 = 4680 tiles of 128 x 128: five groups, the last one partial; a box
+    that is not a power-of-two grid, so the binning divides (cudabrot.cu:308-311)."""
+    w, h, t, passes = 9100, 8300, 16384, 2
+    box = (-2.0, 1.5, -1.6, 1.6)
+    dims = cb.FractalDimensions.make(w, h, *box)
+    size = cb.scatter_workspace_bytes(dims, t, 50)
+    assert size > 0
+    got = _torch_render(cb, w, h, 400, 20, t, passes, size, box=box)
+    cpu = oracle.render(w, h, 400, 20, t, passes, box, omp_threads=0)
+    assert_same(got, cpu)
+
+
 def test_low_level_entry_points_on_torch_memory(cb, oracle):
     """cb_initialize_rng / cb_draw_buddhabrot on caller-owned device memory (torch as the allocator)."""
     import torch
