@@ -145,6 +145,8 @@ def _load():
         "cb_scatter_workspace_bytes": (C.c_size_t, [dims_p, u32, u32]),
         "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp, C.c_size_t, vp, vp]),
         "cb_carry_bytes": (C.c_size_t, [u32]),
+        "cb_draw_buddhabrot_channels": (i32, [dims_p, vp, it_p, i32, vp, u32, u32, vp, i32, vp, C.c_size_t, vp, vp]),
+        "cb_flush_scatter_channels": (i32, [dims_p, vp, i32, u32, vp, C.c_size_t, vp]),
         "cb_renderer_finish": (i32, [vp]),
         "cb_flush_scatter": (i32, [dims_p, vp, u32, vp, C.c_size_t, vp]),
         "cb_renderer_create": (i32, [C.POINTER(vp), i32, dims_p, it_p, u64, u64, u32]),
@@ -178,7 +180,8 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
-    "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states"
+    "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states "
+    "cb_draw_buddhabrot_channels cb_flush_scatter_channels"
 ).split()
 
 
@@ -328,6 +331,25 @@ def set_grayscale_pixels(hist, gamma):
     mx, scale = C.c_uint64(), C.c_double()
     lib.cb_set_grayscale_pixels(a.ctypes.data, w, h, float(gamma), gray.ctypes.data, C.byref(mx), C.byref(scale))
     return gray, int(mx.value), float(scale.value)
+
+
+def draw_buddhabrot_channels(dims, d_hist, windows, d_states, n_threads, samples_per_thread, d_counters=0,
+                             kernel_variant=CB_KERNEL_DEFAULT, stream=0, d_workspace=0, workspace_bytes=0, d_carry=0):
+    """Fused multi-channel launch (N2): windows = [(max_iter, min_iter), ...]; d_hist = len(windows) planes."""
+    arr = (IterationControl * len(windows))(*[IterationControl(int(m), int(c)) for m, c in windows])
+    _check(
+        lib.cb_draw_buddhabrot_channels(C.byref(dims), d_hist, arr, len(windows), d_states, n_threads,
+                                        samples_per_thread, d_counters, kernel_variant, d_workspace, workspace_bytes,
+                                        d_carry, stream),
+        "cb_draw_buddhabrot_channels",
+    )
+
+
+def flush_scatter_channels(dims, d_hist, n_channels, n_threads, d_workspace, workspace_bytes, stream=0):
+    _check(
+        lib.cb_flush_scatter_channels(C.byref(dims), d_hist, n_channels, n_threads, d_workspace, workspace_bytes, stream),
+        "cb_flush_scatter_channels",
+    )
 
 
 def tone_value(count, max_count, gamma):

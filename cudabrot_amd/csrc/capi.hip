@@ -64,7 +64,7 @@ unsigned long long *g_wave_dump = nullptr;
 cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_control *it,
                        cb_pixel *d_hist, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, void *d_workspace,
-                       size_t workspace_bytes, void *d_carry) {
+                       size_t workspace_bytes, void *d_carry, int n_channels = 0) {
   cb::DrawArgs a;
   memset(&a, 0, sizeof(a));
   a.min_real = dims->min_real;
@@ -86,7 +86,7 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.states = reinterpret_cast<uint32_t *>(d_states);
   a.counters = d_counters;
   a.bin = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
-                              cb::draw_wave_count(n_threads));
+                              cb::draw_wave_count(n_threads), n_channels);
   a.wave_dump = g_wave_dump;
   a.check_periodic = 1;
   a.carry = reinterpret_cast<unsigned long long *>(d_carry);
@@ -276,6 +276,62 @@ int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32
                                               cb::draw_wave_count(n_threads));
   return (int) cb::launch_binned_scatter(b, reinterpret_cast<unsigned long long *>(d_hist), dims->w,
                                          dims->h, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
+                                const cb_iteration_control *windows, int n_channels, void *d_states,
+                                uint32_t n_threads, uint32_t samples_per_thread, cb_counters *d_counters,
+                                int kernel_variant, void *d_workspace, size_t workspace_bytes,
+                                void *d_carry, void *stream) {
+  if (!dims || !windows || !d_hist || !d_states) return (int) hipErrorInvalidValue;
+  if (dims->w <= 0 || dims->h <= 0 || n_channels < 1 || n_channels > CB_MAX_CHANNELS) {
+    return (int) hipErrorInvalidValue;
+  }
+  const bool ship = (kernel_variant & CB_KERNEL_FLAG_BURNING_SHIP) != 0;
+  const int base_variant = kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP;
+  if (base_variant != CB_KERNEL_DEFAULT && base_variant != CB_KERNEL_FULL_ITERATE) {
+    return (int) hipErrorInvalidValue;  // the wave-scheduled kernel only
+  }
+  // the kernel iterates to the largest max; what escapes before the smallest min is in no window
+  cb_iteration_control hull = windows[0];
+  for (int j = 1; j < n_channels; ++j) {
+    if (windows[j].max_escape_iterations > hull.max_escape_iterations) {
+      hull.max_escape_iterations = windows[j].max_escape_iterations;
+    }
+    if (windows[j].min_escape_iterations < hull.min_escape_iterations) {
+      hull.min_escape_iterations = windows[j].min_escape_iterations;
+    }
+  }
+  cb::DrawArgs a = make_args(dims, &hull, d_hist, d_states, n_threads, samples_per_thread, d_counters,
+                             d_workspace, workspace_bytes, d_carry, n_channels);
+  a.burning_ship = ship ? 1 : 0;
+  a.n_channels = n_channels;
+  a.plane_pixels = (unsigned long long) dims->w * (unsigned long long) dims->h;
+  for (int j = 0; j < n_channels; ++j) {
+    a.chan_min[j] = windows[j].min_escape_iterations;
+    a.chan_max[j] = windows[j].max_escape_iterations;
+  }
+  if (base_variant == CB_KERNEL_FULL_ITERATE) a.check_periodic = 0;
+  const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
+  return (int) wave(a, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cb_flush_scatter_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist, int n_channels,
+                              uint32_t n_threads, void *d_workspace, size_t workspace_bytes,
+                              void *stream) {
+  if (!dims || !d_hist || dims->w <= 0 || dims->h <= 0 || n_channels < 1 || n_channels > CB_MAX_CHANNELS) {
+    return (int) hipErrorInvalidValue;
+  }
+  cb::BinLayout b = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
+                                        cb::draw_wave_count(n_threads), n_channels);
+  const size_t plane = (size_t) dims->w * (size_t) dims->h;
+  for (int j = 0; j < n_channels; ++j) {  // one pass over the stream per channel: the words tagged with it
+    b.channel = j;
+    const hipError_t e = cb::launch_binned_scatter(b, reinterpret_cast<unsigned long long *>(d_hist) + plane * j,
+                                                   dims->w, dims->h, reinterpret_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return (int) e;
+  }
+  return 0;
 }
 
 int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,

@@ -541,7 +541,10 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 //                       emits for a double division (v_div_scale / v_rcp / Newton steps /
 //                       v_div_fmas / v_div_fixup).
 // The tests re >= min_re, im >= min_im are made on the doubled values (R >= 2 min_re).  The hits of a
-// step are compacted with v_mbcnt and stored side by side (one coalesced store).
+// step are compacted with v_mbcnt and stored side by side (one coalesced store).  The stream word is
+// row << rsh | col | tag (one channel: rsh = 16, tag = 0; fused channels: the orbit's channel set above
+// row and col), and only the lanes of `emit` write (fused channels: not the lanes still measuring
+// their escape index).
 #define CB_REPLAY_BIN_POW2                                \
   "v_fma_f64 %[fx], %[r], %[sx], %[ox]\n\t"               \
   "v_fma_f64 %[fy], %[i], %[sy], %[oy]\n\t"
@@ -587,9 +590,11 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
   "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
-  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
   "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "s_and_b64 vcc, vcc, %[emit]\n\t"                       \
   "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
   "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
   "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
@@ -614,7 +619,9 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 template <bool kPow2>
 __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                              int &p_steps, const Canvas &cv, uint32_t *region,
-                                             uint32_t &fill, uint32_t &lane_steps, uint32_t &hits) {
+                                             uint32_t &fill, uint32_t &lane_steps, uint32_t &hits,
+                                             uint32_t row_shift, uint32_t tag,
+                                             unsigned long long emit) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
@@ -627,6 +634,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  row_shift = __builtin_amdgcn_readfirstlane(row_shift);
+  emit = uniform_u64(emit);
   const double k16 = 16.0;
   if (kPow2) {
     // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
@@ -641,7 +650,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
                  : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
                    [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16)
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
   } else {
     const double sx = uniform_f64(cv.delta_real), sy = uniform_f64(cv.delta_imag);
@@ -655,7 +665,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
                  : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
                    [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16)
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
   }
   lane_steps = cs;
@@ -732,6 +743,36 @@ draw_wave_kernel(DrawArgs a) {
   Orbit po = {0, 0, 0, 0};
   bool p_act = false;
   int p_steps = 0;
+  // Fused channels (DrawArgs::n_channels > 0): an orbit popped from Q2 is first replayed WITHOUT
+  // recording (p_real = false) -- the stages before know its escape index only to a chunk -- and, once
+  // the index k is known, a second time with the set of channels whose window holds k as its tag.
+  const bool multi = a.n_channels > 0;
+  bool p_real = true;
+  uint32_t p_tag = 0u;
+  // lanes of `finished` have just ended a replay pass
+  auto channel_decision = [&](unsigned long long finished) {
+    const bool fin = lane_in(finished);
+    uint32_t set = 0u;
+    if (fin && !p_real) {
+      const int k = p_steps - 1;  // index of the escaping iteration (cudabrot.cu:336)
+      for (int j = 0; j < a.n_channels; ++j) {
+        if (k >= a.chan_min[j] && k < a.chan_max[j]) set |= 1u << j;
+      }
+    }
+    const bool again = fin && !p_real && set != 0u;
+    const unsigned long long again_mask = __ballot(again);
+    const unsigned long long drop_mask = __ballot(fin && !p_real && set == 0u);
+    n_recorded += (unsigned long long) __popcll(again_mask);
+    n_too_fast += (unsigned long long) __popcll(drop_mask);  // in no window (cudabrot.cu:407-408 for every channel)
+    if (again) {  // second pass: the same orbit from z = c, recorded
+      po.r = po.cr;
+      po.i = po.ci;
+      p_steps = 0;
+      p_real = true;
+      p_tag = set << a.bin.e_chan_shift;
+      p_act = true;
+    }
+  };
 
   // Carry-over: pick up the queues and orbit slots the previous launch left behind (DrawArgs::carry).
   static_assert(sizeof(WaveQueues) == kCarryQueueWords * 8, "carry layout follows WaveQueues");
@@ -765,6 +806,8 @@ draw_wave_kernel(DrawArgs a) {
     l_rem[1] = (int) (uint32_t) (pl[16 * 64] >> 32);
     p_steps = (int) (uint32_t) pl[17 * 64];
     p_act = (pl[17 * 64] >> 32) != 0ull;
+    p_tag = (uint32_t) pl[18 * 64];
+    p_real = (pl[18 * 64] >> 32) != 0ull;
   }
 
   for (;;) {
@@ -794,10 +837,12 @@ draw_wave_kernel(DrawArgs a) {
               po.i = po.ci;
               p_steps = 0;
               p_act = true;
+              p_real = !multi;  // fused channels: first pass measures the escape index, nothing is recorded
+              p_tag = 0u;
             }
             q2_head = q2_wrap(q2_head + n);
             q2_count -= n;
-            n_recorded += (unsigned long long) n;
+            if (!multi) n_recorded += (unsigned long long) n;
           }
         }
         const int n_act = __popcll(__ballot(p_act));
@@ -809,15 +854,20 @@ draw_wave_kernel(DrawArgs a) {
         // the result never depends on the workspace size.
         if (kBinned && region_fill + 64u * kReplayBurst <= region_cap) {
           unsigned long long act_mask = __ballot(p_act);
+          const unsigned long long was_act = act_mask;
+          const unsigned long long emit = multi ? __ballot(p_real) : ~0ull;
           uint32_t steps = 0, hits = 0;
           if (cv.pow2_real && cv.pow2_imag) {
-            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                               a.bin.e_row_shift, p_tag, emit);
           } else {
-            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits);
+            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                                a.bin.e_row_shift, p_tag, emit);
           }
           n_replay += steps;
           n_incr += hits;
           p_act = lane_in(act_mask);
+          if (multi) channel_decision(was_act & ~act_mask);
           if (__ballot(p_act && p_steps > max_iter) != 0ull) {
             // cannot happen: the orbit escaped within max_iter steps in an earlier stage
             status |= CB_STATUS_REPLAY_RUNAWAY;
@@ -837,8 +887,18 @@ draw_wave_kernel(DrawArgs a) {
 #else
             const double m4 = mandel_step2(po.cr, po.ci, po.r, po.i);  // cudabrot.cu:357-359
 #endif
-            hit = pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);      // cudabrot.cu:308-311 (halving is exact)
-            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);         // cudabrot.cu:312
+            hit = p_real && pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);  // cudabrot.cu:308-311 (halving is exact)
+            if (hit) {                                                 // cudabrot.cu:312
+              if (!multi) {
+                add_to_pixel(a.hist, cv, row, col, 1ull);
+              } else {
+                for (int j = 0; j < a.n_channels; ++j) {
+                  if ((p_tag >> (a.bin.e_chan_shift + (uint32_t) j)) & 1u) {
+                    add_to_pixel(a.hist + (unsigned long long) j * a.plane_pixels, cv, row, col, 1ull);
+                  }
+                }
+              }
+            }
             p_steps++;
             done = m4 > 16.0;                                          // cudabrot.cu:363
             if (!done && p_steps > max_iter) {
@@ -848,7 +908,9 @@ draw_wave_kernel(DrawArgs a) {
             if (done) p_act = false;
           }
           n_incr += (unsigned long long) __popcll(__ballot(hit));
-          if (__ballot(done) != 0ull && q2_count > 0) break;
+          const unsigned long long done_mask = __ballot(done);
+          if (multi && done_mask != 0ull) channel_decision(done_mask);
+          if (done_mask != 0ull && q2_count > 0) break;
         }
       }
       if (kTimed) t_replay += __builtin_amdgcn_s_memtime() - t0;
@@ -1161,6 +1223,7 @@ draw_wave_kernel(DrawArgs a) {
     pl[15 * 64] = (unsigned long long) __double_as_longlong(po.i);
     pl[16 * 64] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
     pl[17 * 64] = (unsigned long long) (uint32_t) p_steps | ((unsigned long long) (p_act ? 1u : 0u) << 32);
+    pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32);
   }
   const unsigned long long skipped_total = wave_sum(skipped_steps);
   if (a.counters && lane_id() == 0) {

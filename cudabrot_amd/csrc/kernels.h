@@ -46,6 +46,11 @@ struct BinLayout {
   uint32_t n_groups;
   uint32_t max_regions;   // size of the region table (level B; = n_waves with one level)
   uint32_t count_stride;  // row length of `count`
+  // Layout of a stream word: col in the low bits, row above it (e_row_shift), and -- fused multi-channel
+  // renders only -- the set of channels the orbit belongs to above both (e_chan_shift).  One channel:
+  // row << 16 | col.  `channel` (>= 0) makes a flush take only the words whose set holds that channel.
+  uint32_t e_row_shift, e_col_mask, e_row_mask, e_chan_shift;
+  int channel;
   uint32_t *wave_count;           // [n_waves]            entries written by each wave
   uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
   uint32_t *a_count;              // [n_groups*16][n_waves]  level A counts, then prefix over waves
@@ -68,7 +73,7 @@ struct BinLayout {
 size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave);
 // Carves `bytes` at `workspace` into a BinLayout (enabled = 0 if it is too small or the canvas does
 // not qualify).
-BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves);
+BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves, int n_channels = 0);
 // count -> scan -> scatter -> accumulate on `stream`, after the draw kernel that filled the stream.
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream);
@@ -104,11 +109,18 @@ struct DrawArgs {
   // the reference's RENDER_BURNING_SHIP variant (cudabrot.cu:15-17); read by draw_simple_kernel, the
   // wave kernel has a build of its own for it (launch_draw_wave_ship)
   int burning_ship;
+  // Fused multi-channel render: n_channels > 0 windows [chan_min[j], chan_max[j]) of
+  // the escape index; max_iter / min_iter above are then the largest max and the smallest min, and an
+  // orbit is replayed once into every channel whose window holds its escape index.  hist is
+  // n_channels planes of plane_pixels counters.
+  int n_channels;
+  int chan_min[CB_MAX_CHANNELS], chan_max[CB_MAX_CHANNELS];
+  unsigned long long plane_pixels;
 };
 
 constexpr uint32_t kCarryHeaderWords = 8;
 constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 128 + 2 * 192);  // = sizeof(WaveQueues) / 8
-constexpr uint32_t kCarryLanePlanes = 18;
+constexpr uint32_t kCarryLanePlanes = 19;
 constexpr uint32_t kCarryWordsPerWave = kCarryHeaderWords + kCarryQueueWords + kCarryLanePlanes * 64;
 
 constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup

@@ -50,11 +50,15 @@ constexpr uint32_t kRegionEntries = 262144;        // level-B region: 32 chunks
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-__device__ __forceinline__ uint32_t tile_of(uint32_t e, uint32_t tiles_x) {
-  return ((e >> 16) >> kTileShift) * tiles_x + ((e & 0xffffu) >> kTileShift);
+// stream word -> tile, in-tile offset (BinLayout: e_* describe the word), and the channel filter
+__device__ __forceinline__ uint32_t tile_of(uint32_t e, const BinLayout &b) {
+  return (((e >> b.e_row_shift) & b.e_row_mask) >> kTileShift) * b.tiles_x + ((e & b.e_col_mask) >> kTileShift);
 }
-__device__ __forceinline__ uint32_t offset_of(uint32_t e) {
-  return (((e >> 16) & (kTileSize - 1u)) << kTileShift) | (e & (kTileSize - 1u));
+__device__ __forceinline__ uint32_t offset_of(uint32_t e, const BinLayout &b) {
+  return (((e >> b.e_row_shift) & (kTileSize - 1u)) << kTileShift) | (e & (kTileSize - 1u));
+}
+__device__ __forceinline__ bool taken(uint32_t e, const BinLayout &b) {
+  return b.channel < 0 || (((e >> b.e_chan_shift) >> b.channel) & 1u) != 0u;
 }
 __device__ __forceinline__ void lds_inc(uint32_t *p) {
   __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
@@ -87,7 +91,7 @@ struct Pass {
   // j: the entry's index in its region.  The replica must be a function of the entry alone (both the
   // count and the scatter kernel evaluate it, with different thread mappings).
   __device__ static uint32_t key(const BinLayout &b, uint32_t e, uint32_t k0, uint32_t j) {
-    const uint32_t t = tile_of(e, b.tiles_x);
+    const uint32_t t = tile_of(e, b);
     if (kLevelA) return ((t >> kGroupShift) * kReplicas) | (j & (kReplicas - 1u));
     return t - k0;
   }
@@ -156,19 +160,19 @@ __global__ void __launch_bounds__(kScatterThreads) bin_count_kernel(BinLayout b)
   // entries up to a 16-byte boundary, then four per load, then the tail (level-B regions start anywhere)
   uint32_t head = (4u - (uint32_t) ((reinterpret_cast<uintptr_t>(src) >> 2) & 3u)) & 3u;
   if (head > n) head = n;
-  if (threadIdx.x < head) lds_inc(&lds[P::key(b, src[threadIdx.x], k0, threadIdx.x)]);
+  if (threadIdx.x < head && taken(src[threadIdx.x], b)) lds_inc(&lds[P::key(b, src[threadIdx.x], k0, threadIdx.x)]);
   const uint32_t n4 = (n - head) >> 2;
   const uint4 *src4 = reinterpret_cast<const uint4 *>(src + head);
   for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
     const uint4 v = src4[i];
     const uint32_t j = head + (i << 2);
-    lds_inc(&lds[P::key(b, v.x, k0, j)]);
-    lds_inc(&lds[P::key(b, v.y, k0, j + 1u)]);
-    lds_inc(&lds[P::key(b, v.z, k0, j + 2u)]);
-    lds_inc(&lds[P::key(b, v.w, k0, j + 3u)]);
+    if (taken(v.x, b)) lds_inc(&lds[P::key(b, v.x, k0, j)]);
+    if (taken(v.y, b)) lds_inc(&lds[P::key(b, v.y, k0, j + 1u)]);
+    if (taken(v.z, b)) lds_inc(&lds[P::key(b, v.z, k0, j + 2u)]);
+    if (taken(v.w, b)) lds_inc(&lds[P::key(b, v.w, k0, j + 3u)]);
   }
   for (uint32_t i = head + (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
-    lds_inc(&lds[P::key(b, src[i], k0, i)]);
+    if (taken(src[i], b)) lds_inc(&lds[P::key(b, src[i], k0, i)]);
   }
   __syncthreads();
   // key-major: the scan over regions reads each key's row contiguously
@@ -323,6 +327,7 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
     __syncthreads();
     // 1. rank of every entry inside (chunk, key)
     uint32_t e[kPerThread], rank[kPerThread], key[kPerThread];
+    uint32_t taken_in_chunk = m;
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
@@ -332,8 +337,8 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
       rank[k] = 0u;
-      key[k] = 0u;
-      if (i < m) {
+      key[k] = ~0u;  // not part of this flush (beyond the chunk, or another channel's word)
+      if (i < m && taken(e[k], b)) {
         key[k] = P::key(b, e[k], k0, base + i);
         rank[k] = __hip_atomic_fetch_add(&cnt[key[k]], 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
@@ -355,28 +360,28 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
           run += cnt[t0 + k];
         }
       }
+      taken_in_chunk = total;
     }
     __syncthreads();
     // 3. sort the chunk in LDS: destination place and payload, key by key
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
-      const uint32_t i = k * kScatterThreads + threadIdx.x;
-      if (i < m) {
+      if (key[k] != ~0u) {
         const uint32_t lp = lstart[key[k]] + rank[k];
         pos[lp] = cursor[key[k]] + rank[k];
         if (kLevelA) {
           pay32[lp] = e[k];
         } else {
-          pay16[lp] = (uint16_t) offset_of(e[k]);
+          pay16[lp] = (uint16_t) offset_of(e[k], b);
         }
       }
     }
     __syncthreads();
     // 4. write the runs out (consecutive lanes -> consecutive places of a run) and advance cursors
     if (kLevelA) {
-      for (uint32_t i = threadIdx.x; i < m; i += kScatterThreads) b.grouped[pos[i]] = pay32[i];
+      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) b.grouped[pos[i]] = pay32[i];
     } else {
-      for (uint32_t i = threadIdx.x; i < m; i += kScatterThreads) b.sorted[pos[i]] = pay16[i];
+      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) b.sorted[pos[i]] = pay16[i];
     }
     for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) cursor[t] += cnt[t];
     __syncthreads();
@@ -514,9 +519,24 @@ size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wa
   return fixed_bytes(s, n_waves, max_regions_for(s, n_waves, entries)) + entries * bytes_per_entry(s) + 8192;
 }
 
-BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves) {
+BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves, int n_channels) {
   BinLayout b;
   memset(&b, 0, sizeof(b));
+  b.channel = -1;
+  b.e_row_shift = 16;
+  b.e_col_mask = 0xffffu;
+  b.e_row_mask = 0xffffu;
+  b.e_chan_shift = 0;
+  if (n_channels > 0) {  // [channel set | row | col], fields as narrow as the canvas allows
+    uint32_t cb_ = 0, rb = 0;
+    while ((1u << cb_) < (uint32_t) (w > 1 ? w : 1)) ++cb_;
+    while ((1u << rb) < (uint32_t) (h > 1 ? h : 1)) ++rb;
+    if (w <= 0 || h <= 0 || cb_ + rb + (uint32_t) n_channels > 32u) return b;  // no room: direct atomics
+    b.e_row_shift = cb_;
+    b.e_col_mask = (1u << cb_) - 1u;
+    b.e_row_mask = (1u << rb) - 1u;
+    b.e_chan_shift = cb_ + rb;
+  }
   b.slice_entries = kSliceEntriesDefault;
   if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob
     const long v = atol(e);

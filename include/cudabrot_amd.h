@@ -86,6 +86,9 @@ typedef struct {
                                     sample is iterated to max_iter as the reference does (same result;
                                     for measuring the iterate loop against the fp64 roofline)        */
 
+/* Fused multi-channel renders: at most this many (max, min) windows per launch. */
+#define CB_MAX_CHANNELS 4
+
 /* OR-ed into a kernel variant: the reference's RENDER_BURNING_SHIP build (cudabrot.cu:15-17 -- there a
  * compile-time switch): |real|, |imag| before every step and no cardioid / bulb shortcut. */
 #define CB_KERNEL_FLAG_BURNING_SHIP 0x100
@@ -143,6 +146,24 @@ size_t cb_carry_bytes(uint32_t n_threads);
  * call.  A no-op for a workspace the draw call could not use. */
 int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32_t n_threads,
                      void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---- Fused multi-channel render ---------------------------------------------- *
+ *
+ * The reference's colour recipe (generate_hires_color_image.sh:27-59) runs the program once per
+ * channel with different -m / -c.  All runs draw the same sample stream, so one pass can serve them:
+ * every sample is iterated once up to the largest max, and its orbit is replayed once into every
+ * channel j whose window windows[j].min <= k < windows[j].max holds the escape index k.  d_hist is
+ * n_channels planes of w*h counters, plane j = what cb_draw_buddhabrot would add with windows[j].
+ * The wave-scheduled kernel only (variant flags as above); cb_flush_scatter_channels after each
+ * launch that was given a workspace (sized by cb_scatter_workspace_bytes). */
+int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
+                                const cb_iteration_control *windows, int n_channels, void *d_states,
+                                uint32_t n_threads, uint32_t samples_per_thread, cb_counters *d_counters,
+                                int kernel_variant, void *d_workspace, size_t workspace_bytes,
+                                void *d_carry, void *stream);
+int cb_flush_scatter_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist, int n_channels,
+                              uint32_t n_threads, void *d_workspace, size_t workspace_bytes,
+                              void *stream);
 
 /* ---- Renderer: SetupCUDA + RenderImage + the -s buffer, as an owned object ---------------------- */
 
