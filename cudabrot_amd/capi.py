@@ -150,6 +150,8 @@ def _load():
         "cb_renderer_finish": (i32, [vp]),
         "cb_flush_scatter": (i32, [dims_p, vp, u32, vp, C.c_size_t, vp]),
         "cb_renderer_create": (i32, [C.POINTER(vp), i32, dims_p, it_p, u64, u64, u32]),
+        "cb_renderer_create_channels": (i32, [C.POINTER(vp), i32, dims_p, it_p, i32, u64, u64, u32]),
+        "cb_renderer_grayscale_plane": (i32, [vp, i32, C.c_double, i32, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cb_renderer_render_passes": (i32, [vp, u32, i32]),
         "cb_renderer_read_histogram": (i32, [vp, vp]),
         "cb_renderer_write_histogram": (i32, [vp, vp]),
@@ -181,7 +183,7 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
     "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states "
-    "cb_draw_buddhabrot_channels cb_flush_scatter_channels"
+    "cb_draw_buddhabrot_channels cb_flush_scatter_channels cb_renderer_create_channels cb_renderer_grayscale_plane"
 ).split()
 
 
@@ -245,15 +247,27 @@ class Renderer:
 
     def __init__(self, dims, iterations, device=0, seed=CB_DEFAULT_RNG_SEED, first_subsequence=0,
                  n_threads=CB_DEFAULT_THREADS):
+        """iterations: an IterationControl, or -- fused multi-channel render (N2) -- a list of (max, min)
+        windows; read_histogram then returns one plane per window ([k, h, w])."""
         self.dims = dims
         self.iterations = iterations
         self.n_threads = n_threads
         self._h = C.c_void_p()
-        _check(
-            lib.cb_renderer_create(C.byref(self._h), device, C.byref(dims), C.byref(iterations), seed,
-                                   first_subsequence, n_threads),
-            "cb_renderer_create",
-        )
+        if isinstance(iterations, IterationControl):
+            self.n_channels = 0
+            _check(
+                lib.cb_renderer_create(C.byref(self._h), device, C.byref(dims), C.byref(iterations), seed,
+                                       first_subsequence, n_threads),
+                "cb_renderer_create",
+            )
+        else:
+            self.n_channels = len(iterations)
+            arr = (IterationControl * len(iterations))(*[IterationControl(int(m), int(c)) for m, c in iterations])
+            _check(
+                lib.cb_renderer_create_channels(C.byref(self._h), device, C.byref(dims), arr, len(iterations), seed,
+                                                first_subsequence, n_threads),
+                "cb_renderer_create_channels",
+            )
 
     def render_passes(self, passes, kernel_variant=CB_KERNEL_DEFAULT):
         _check(lib.cb_renderer_render_passes(self._h, passes, kernel_variant), "cb_renderer_render_passes")
@@ -263,8 +277,11 @@ class Renderer:
         _check(lib.cb_renderer_finish(self._h), "cb_renderer_finish")
 
     def read_histogram(self):
-        out = np.empty(self.dims.w * self.dims.h, dtype=np.uint64)
+        planes = self.n_channels or 1
+        out = np.empty(planes * self.dims.w * self.dims.h, dtype=np.uint64)
         _check(lib.cb_renderer_read_histogram(self._h, out.ctypes.data), "cb_renderer_read_histogram")
+        if self.n_channels:
+            return out.reshape(planes, self.dims.h, self.dims.w)
         return out.reshape(self.dims.h, self.dims.w)
 
     def read_rng_states(self):
@@ -279,20 +296,20 @@ class Renderer:
             raise ValueError("generator state blob does not match n_threads")
         _check(lib.cb_renderer_write_rng_states(self._h, a.ctypes.data), "cb_renderer_write_rng_states")
 
-    def grayscale_image(self, gamma, mode=0):
+    def grayscale_image(self, gamma, mode=0, plane=0):
         """Device tone map (N1) -> (big-endian u16 image [h,w] = the PGM body, max count, scale)."""
         gray = np.empty((self.dims.h, self.dims.w), dtype=">u2")
         mx, scale = C.c_uint64(), C.c_double()
         _check(
-            lib.cb_renderer_grayscale_image(self._h, float(gamma), int(mode), gray.ctypes.data, C.byref(mx),
-                                            C.byref(scale)),
-            "cb_renderer_grayscale_image",
+            lib.cb_renderer_grayscale_plane(self._h, int(plane), float(gamma), int(mode), gray.ctypes.data,
+                                            C.byref(mx), C.byref(scale)),
+            "cb_renderer_grayscale_plane",
         )
         return gray, int(mx.value), float(scale.value)
 
     def write_histogram(self, hist):
         a = np.ascontiguousarray(hist, dtype=np.uint64).reshape(-1)
-        if a.size != self.dims.w * self.dims.h:
+        if a.size != (self.n_channels or 1) * self.dims.w * self.dims.h:
             raise ValueError("histogram size does not match the canvas")
         _check(lib.cb_renderer_write_histogram(self._h, a.ctypes.data), "cb_renderer_write_histogram")
 

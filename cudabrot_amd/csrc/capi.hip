@@ -124,6 +124,9 @@ struct cb_renderer {
   void *d_carry;
   bool carry_pending;
   int carry_variant;
+  // fused multi-channel render: n_channels > 0 windows, d_hist holds that many planes
+  int n_channels;
+  cb_iteration_control windows[CB_MAX_CHANNELS];
 };
 
 namespace {
@@ -139,10 +142,18 @@ int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
     CB_TRY(hipStreamWaitEvent(r->stream, r->flush_done[k], 0));
     r->flush_pending[k] = false;
   }
-  int rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
-                              passes * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
-                              deferred ? r->d_workspace[k] : nullptr, r->workspace_bytes,
-                              wave ? r->d_carry : nullptr, r->stream);
+  int rc;
+  if (r->n_channels > 0) {
+    rc = cb_draw_buddhabrot_channels(&r->dims, r->d_hist, r->windows, r->n_channels, r->d_states,
+                                     r->n_threads, passes * CB_SAMPLES_PER_THREAD, r->d_counters,
+                                     kernel_variant, deferred ? r->d_workspace[k] : nullptr,
+                                     r->workspace_bytes, r->d_carry, r->stream);
+  } else {
+    rc = cb_draw_buddhabrot(&r->dims, r->d_hist, &r->iterations, r->d_states, r->n_threads,
+                            passes * CB_SAMPLES_PER_THREAD, r->d_counters, kernel_variant,
+                            deferred ? r->d_workspace[k] : nullptr, r->workspace_bytes,
+                            wave ? r->d_carry : nullptr, r->stream);
+  }
   if (rc) return rc;
   if (wave && r->d_carry) {
     r->carry_pending = passes != 0;
@@ -151,8 +162,13 @@ int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
   if (deferred) {
     CB_TRY(hipEventRecord(r->draw_done[k], r->stream));
     CB_TRY(hipStreamWaitEvent(r->flush_stream, r->draw_done[k], 0));
-    rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace[k], r->workspace_bytes,
-                          r->flush_stream);
+    if (r->n_channels > 0) {
+      rc = cb_flush_scatter_channels(&r->dims, r->d_hist, r->n_channels, r->n_threads, r->d_workspace[k],
+                                     r->workspace_bytes, r->flush_stream);
+    } else {
+      rc = cb_flush_scatter(&r->dims, r->d_hist, r->n_threads, r->d_workspace[k], r->workspace_bytes,
+                            r->flush_stream);
+    }
     if (rc) return rc;
     CB_TRY(hipEventRecord(r->flush_done[k], r->flush_stream));
     r->flush_pending[k] = true;
@@ -337,7 +353,14 @@ int cb_flush_scatter_channels(const cb_fractal_dimensions *dims, cb_pixel *d_his
 int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
                        const cb_iteration_control *iterations, uint64_t seed,
                        uint64_t first_subsequence, uint32_t n_threads) {
-  if (!out || !dims || !iterations || dims->w <= 0 || dims->h <= 0 || n_threads == 0) {
+  return cb_renderer_create_channels(out, device, dims, iterations, 0, seed, first_subsequence, n_threads);
+}
+
+int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
+                                const cb_iteration_control *iterations, int n_channels, uint64_t seed,
+                                uint64_t first_subsequence, uint32_t n_threads) {
+  if (!out || !dims || !iterations || dims->w <= 0 || dims->h <= 0 || n_threads == 0 || n_channels < 0 ||
+      n_channels > CB_MAX_CHANNELS) {
     return (int) hipErrorInvalidValue;
   }
   *out = nullptr;
@@ -348,8 +371,10 @@ int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimension
   r->device = device;
   r->dims = *dims;
   r->iterations = *iterations;
+  r->n_channels = n_channels;
+  for (int j = 0; j < n_channels; ++j) r->windows[j] = iterations[j];
   r->n_threads = n_threads;
-  const size_t hist_bytes = (size_t) dims->w * (size_t) dims->h * sizeof(cb_pixel);
+  const size_t hist_bytes = (size_t) dims->w * (size_t) dims->h * sizeof(cb_pixel) * (size_t) (n_channels ? n_channels : 1);
   hipError_t e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->flush_stream, hipStreamNonBlocking);
   for (int k = 0; k < 2 && e == hipSuccess; ++k) {
@@ -455,14 +480,22 @@ int cb_renderer_read_histogram(cb_renderer *r, cb_pixel *host_out) {
     int rc = finish(r);
     if (rc) return rc;
   }
-  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
+  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel) *
+                       (size_t) (r->n_channels ? r->n_channels : 1);
   CB_TRY(hipMemcpyAsync(host_out, r->d_hist, bytes, hipMemcpyDeviceToHost, r->stream));
   return (int) hipStreamSynchronize(r->stream);
 }
 
 int cb_renderer_grayscale_image(cb_renderer *r, double gamma, int mode, uint16_t *host_gray_be,
                                 uint64_t *max_out, double *scale_out) {
-  if (!r || !host_gray_be) return (int) hipErrorInvalidValue;
+  return cb_renderer_grayscale_plane(r, 0, gamma, mode, host_gray_be, max_out, scale_out);
+}
+
+int cb_renderer_grayscale_plane(cb_renderer *r, int plane, double gamma, int mode, uint16_t *host_gray_be,
+                                uint64_t *max_out, double *scale_out) {
+  if (!r || !host_gray_be || plane < 0 || plane >= (r->n_channels ? r->n_channels : 1)) {
+    return (int) hipErrorInvalidValue;
+  }
   CB_TRY(hipSetDevice(r->device));
   {
     int rc = finish(r);
@@ -471,8 +504,8 @@ int cb_renderer_grayscale_image(cb_renderer *r, double gamma, int mode, uint16_t
   const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(uint16_t);
   uint16_t *d_gray = nullptr;
   CB_TRY(hipMalloc(reinterpret_cast<void **>(&d_gray), bytes));
-  int rc = cb_tone_map_device(r->d_hist, r->dims.w, r->dims.h, gamma, mode, d_gray, max_out, scale_out,
-                              r->stream);
+  int rc = cb_tone_map_device(r->d_hist + (size_t) plane * (size_t) r->dims.w * (size_t) r->dims.h, r->dims.w,
+                              r->dims.h, gamma, mode, d_gray, max_out, scale_out, r->stream);
   if (rc == 0) rc = (int) hipMemcpyAsync(host_gray_be, d_gray, bytes, hipMemcpyDeviceToHost, r->stream);
   if (rc == 0) rc = (int) hipStreamSynchronize(r->stream);
   (void) hipFree(d_gray);
@@ -486,7 +519,8 @@ int cb_renderer_write_histogram(cb_renderer *r, const cb_pixel *host_in) {
     int rc = finish(r);
     if (rc) return rc;
   }
-  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel);
+  const size_t bytes = (size_t) r->dims.w * (size_t) r->dims.h * sizeof(cb_pixel) *
+                       (size_t) (r->n_channels ? r->n_channels : 1);
   CB_TRY(hipMemcpyAsync(r->d_hist, host_in, bytes, hipMemcpyHostToDevice, r->stream));
   return (int) hipStreamSynchronize(r->stream);
 }

@@ -12,7 +12,7 @@
 //  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
 //    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
 //  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
-//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship.
+//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship, --channel MAX:MIN:FILE.
 #include <errno.h>
 #include <signal.h>
 #include <stdint.h>
@@ -43,6 +43,11 @@ struct Settings {
   int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
   bool print_stats = false;                         // --stats  (extension)
   bool burning_ship = false;                        // --burning-ship (extension; cudabrot.cu:15-17)
+  // --channel MAX:MIN:FILE (extension, repeatable): fused multi-channel render, one image per window
+  int n_channels = 0;
+  cb_iteration_control channel_window[CB_MAX_CHANNELS] = {};
+  std::string channel_file[CB_MAX_CHANNELS];
+  bool bad_channel = false;
   uint64_t seed = CB_DEFAULT_RNG_SEED;              // --seed (extension; cudabrot.cu:37)
   const char *rng_state_file = nullptr;             // --rng-state (extension): true-resume sidecar
   int tone_mode = CB_TONE_AUTO;                     // --tonemap (extension): device table / thresholds
@@ -156,6 +161,18 @@ const std::vector<Flag> &flag_table() {
        }},
       {"--stats", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.print_stats = true; }},
+      {"--channel", Value::kText, nullptr, false,
+       [](Settings &s, long, double, const char *t) {
+         int mx = 0, mn = 0, used = 0;
+         if (s.n_channels >= CB_MAX_CHANNELS || sscanf(t, "%d:%d:%n", &mx, &mn, &used) < 2 || used == 0 ||
+             t[used] == 0) {
+           s.bad_channel = true;
+           return;
+         }
+         s.channel_window[s.n_channels] = {mx, mn};
+         s.channel_file[s.n_channels] = t + used;
+         s.n_channels++;
+       }},
       {"--burning-ship", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.burning_ship = true; }},
       {"--seed", Value::kInt, nullptr, false,
@@ -229,6 +246,10 @@ Settings parse_arguments(int argc, char **argv) {
       }
     }
     flag->store(s, as_int, as_double, text);
+    if (s.bad_channel) {
+      printf("Invalid channel (want MAX:MIN:FILE, at most %d of them): %s\n", CB_MAX_CHANNELS, text);
+      usage_and_exit(argv[0]);
+    }
     if (flag->revalidates_canvas && !canvas_ok(s)) usage_and_exit(argv[0]);
   }
   return s;
@@ -251,8 +272,14 @@ class Run {
   ~Run() { release(); }
 
   int execute() {
+    int max_iterations = cfg_.iterations.max_escape_iterations;
+    for (int j = 0; j < cfg_.n_channels; ++j) {
+      if (j == 0 || cfg_.channel_window[j].max_escape_iterations > max_iterations) {
+        max_iterations = cfg_.channel_window[j].max_escape_iterations;
+      }
+    }
     printf("Creating %dx%d image, %d max iterations.\n", cfg_.canvas.w, cfg_.canvas.h,
-           cfg_.iterations.max_escape_iterations);  // cudabrot.cu:779-780
+           max_iterations);  // cudabrot.cu:779-780
     printf("Calculating image...\n");
     setup();
     load_inprogress();
@@ -260,9 +287,13 @@ class Run {
     render();
     save_inprogress();
     save_rng_state();
-    printf("Saving image.\n");
-    save_image();
-    printf("Done! Output image saved: %s\n", cfg_.output_image);
+    if (cfg_.n_channels > 0) {
+      save_channels();
+    } else {
+      printf("Saving image.\n");
+      save_image(cfg_.output_image);
+      printf("Done! Output image saved: %s\n", cfg_.output_image);
+    }
     release();
     return 0;
   }
@@ -277,7 +308,8 @@ class Run {
   bool need_host_counts() const { return cfg_.inprogress_file != nullptr || cfg_.host_tonemap; }
 
   uint64_t pixel_count() const { return (uint64_t) cfg_.canvas.w * (uint64_t) cfg_.canvas.h; }
-  uint64_t buffer_bytes() const { return pixel_count() * sizeof(cb_pixel); }
+  uint64_t planes() const { return cfg_.n_channels > 0 ? (uint64_t) cfg_.n_channels : 1u; }
+  uint64_t buffer_bytes() const { return planes() * pixel_count() * sizeof(cb_pixel); }
 
   void release() {  // cudabrot.cu:112-119
     cb_renderer_destroy(renderer_);
@@ -308,8 +340,13 @@ class Run {
     float cpu_mib = (float) (buffer_bytes() + pixel_count() * sizeof(uint16_t));
     cpu_mib /= (1024.0 * 1024.0);
     printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
-    CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
-                                cfg_.seed, 0, CB_DEFAULT_THREADS));
+    if (cfg_.n_channels > 0) {
+      CB_CHECK(cb_renderer_create_channels(&renderer_, cfg_.device, &cfg_.canvas, cfg_.channel_window,
+                                           cfg_.n_channels, cfg_.seed, 0, CB_DEFAULT_THREADS));
+    } else {
+      CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
+                                  cfg_.seed, 0, CB_DEFAULT_THREADS));
+    }
     if (need_host_counts()) {
       counts_ = (cb_pixel *) calloc(1, buffer_bytes());
       if (!counts_) die();
@@ -350,7 +387,7 @@ class Run {
     }
     const uint64_t narrow_bytes = pixel_count() * sizeof(uint32_t);
     bool ok;
-    if ((uint64_t) size == narrow_bytes) {
+    if ((uint64_t) size == narrow_bytes && cfg_.n_channels == 0) {
       // written by the reference: uint32 counters, widened here
       std::vector<uint32_t> narrow(pixel_count());
       ok = fread(narrow.data(), narrow_bytes, 1, f) == 1;
@@ -505,17 +542,34 @@ class Run {
     passes_this_run_ = (uint64_t) done;
     printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
     if (cfg_.print_stats) print_stats();
+    if (cfg_.n_channels == 0) tone_map(0);
+  }
+
+  void tone_map(int plane) {
     uint64_t max = 0;
     double scale = 0.0;
     if (cfg_.host_tonemap) {
-      cb_set_grayscale_pixels(counts_, cfg_.canvas.w, cfg_.canvas.h, cfg_.gamma_correction, gray_,
-                              &max, &scale);
+      cb_set_grayscale_pixels(counts_ + (uint64_t) plane * pixel_count(), cfg_.canvas.w, cfg_.canvas.h,
+                              cfg_.gamma_correction, gray_, &max, &scale);
+      gray_is_big_endian_ = false;
     } else {  // tone map on the device: only the 16-bit image crosses to the host
-      CB_CHECK(cb_renderer_grayscale_image(renderer_, cfg_.gamma_correction, cfg_.tone_mode, gray_,
+      CB_CHECK(cb_renderer_grayscale_plane(renderer_, plane, cfg_.gamma_correction, cfg_.tone_mode, gray_,
                                            &max, &scale));
       gray_is_big_endian_ = true;
     }
     printf("Max value: %lu, scale: %f\n", (unsigned long) max, scale);  // cudabrot.cu:437
+  }
+
+  // Fused multi-channel render: one image per window.
+  void save_channels() {
+    for (int j = 0; j < cfg_.n_channels; ++j) {
+      printf("Channel %d: %d max iterations, %d min iterations.\n", j,
+             cfg_.channel_window[j].max_escape_iterations, cfg_.channel_window[j].min_escape_iterations);
+      tone_map(j);
+      printf("Saving image.\n");
+      save_image(cfg_.channel_file[j].c_str());
+      printf("Done! Output image saved: %s\n", cfg_.channel_file[j].c_str());
+    }
   }
 
   void print_stats() {
@@ -539,12 +593,11 @@ class Run {
             (unsigned long long) c.rt_wave_life_sum);
   }
 
-  void save_image() {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0
+  void save_image(const char *path) {  // cudabrot.cu:548-577: failures are reported and the run still ends with 0
     static const char *const kWhy[] = {nullptr, "Failed opening output image.",
                                        "Failed writing pgm header.", "Failed writing pixel data."};
-    const int rc = gray_is_big_endian_
-                       ? cb_save_image_be(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h)
-                       : cb_save_image(cfg_.output_image, gray_, cfg_.canvas.w, cfg_.canvas.h);
+    const int rc = gray_is_big_endian_ ? cb_save_image_be(path, gray_, cfg_.canvas.w, cfg_.canvas.h)
+                                       : cb_save_image(path, gray_, cfg_.canvas.w, cfg_.canvas.h);
     if (rc >= 1 && rc <= 3) printf("%s\n", kWhy[rc]);
   }
 #undef CB_CHECK

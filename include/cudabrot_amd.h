@@ -174,6 +174,11 @@ typedef struct cb_renderer cb_renderer;
 int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
                        const cb_iteration_control *iterations, uint64_t seed,
                        uint64_t first_subsequence, uint32_t n_threads);
+/* The same for a fused multi-channel render: n_channels (1..CB_MAX_CHANNELS) windows; the histogram is
+ * n_channels planes of w*h counters, in read/write_histogram too (n_channels = 0: cb_renderer_create). */
+int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_dimensions *dims,
+                                const cb_iteration_control *windows, int n_channels, uint64_t seed,
+                                uint64_t first_subsequence, uint32_t n_threads);
 /* `passes` iterations of the loop body of RenderImage (cudabrot.cu:483-487), fused into as few
  * launches as possible; returns after the device has finished them.  Orbits still in flight are
  * carried to the next call; cb_renderer_finish (called by the read/write functions below) completes
@@ -229,6 +234,10 @@ int cb_tone_map_device(const cb_pixel *d_hist, int w, int h, double gamma, int m
 /* The same for a renderer's histogram (finishes carried work first); host_gray_be receives the
  * w*h big-endian pixels: 2 bytes per pixel cross PCIe instead of 8. */
 int cb_renderer_grayscale_image(cb_renderer *r, double gamma, int mode, uint16_t *host_gray_be,
+                                uint64_t *max_out, double *scale_out);
+
+/* ... for plane `plane` of a multi-channel renderer. */
+int cb_renderer_grayscale_plane(cb_renderer *r, int plane, double gamma, int mode, uint16_t *host_gray_be,
                                 uint64_t *max_out, double *scale_out);
 
 const char *cb_error_string(int code);

@@ -83,3 +83,20 @@ def test_too_many_channels_or_the_simple_kernel_are_rejected(cb):
         cb.draw_buddhabrot_channels(dims, 8, [(100, 20)] * 5, 8, 64, 50)
     with pytest.raises(cb.CudabrotError):
         cb.draw_buddhabrot_channels(dims, 8, [(100, 20)], 8, 64, 50, kernel_variant=cb.CB_KERNEL_SIMPLE)
+
+
+def test_renderer_with_channels_pipelines_launches_and_tone_maps_each_plane(cb, oracle):
+    """cb_renderer_create_channels: the owned-object form (two workspaces, carry, lazy drain)."""
+    windows = [(120, 20), (900, 120)]
+    w, h, t, passes = 256, 192, 8192, 70          # 70 passes = two launches (64 + 6)
+    dims = cb.FractalDimensions.make(w, h)
+    with cb.Renderer(dims, windows, n_threads=t) as r:
+        r.render_passes(passes)
+        body, mx, _ = r.grayscale_image(2.2, plane=1)
+        planes = r.read_histogram()
+    assert planes.shape == (2, h, w)
+    for j, (m, c) in enumerate(windows):
+        ref, _ = oracle.render(w, h, m, c, t, passes, omp_threads=0)
+        assert np.array_equal(planes[j], ref)
+    gray, mx_ref, _ = oracle.set_grayscale_pixels(planes[1], 2.2)
+    assert mx == mx_ref and np.array_equal(body.astype(np.uint16), gray)

@@ -100,6 +100,30 @@ def test_burning_ship_flag(exe, oracle, tmp_path):
     assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
 
 
+def test_channel_flags_render_the_colour_recipe_in_one_run(exe, oracle, tmp_path):
+    """--channel MAX:MIN:FILE (extension): what generate_hires_color_image.sh does with
+    three runs -- every image equals the separate run with that -m / -c and the same passes."""
+    outs = [str(tmp_path / ("c%d.pgm" % j)) for j in range(3)]
+    windows = [(100, 20), (400, 100), (1500, 400)]
+    buf = str(tmp_path / "planes.bin")
+    args = []
+    for (m, c), o in zip(windows, outs):
+        args += ["--channel", "%d:%d:%s" % (m, c, o)]
+    r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-g", "2.2", "-s", buf, *args)
+    assert r.returncode == 0, r.stdout
+    assert "Creating 300x200 image, 1500 max iterations." in r.stdout
+    planes = np.fromfile(buf, dtype=np.uint64).reshape(3, 200, 300)
+    for j, ((m, c), o) in enumerate(zip(windows, outs)):
+        hist, _ = oracle.render(300, 200, m, c, T, 2, omp_threads=0)
+        assert np.array_equal(planes[j], hist)
+        gray, mx, scale = oracle.set_grayscale_pixels(hist, 2.2)
+        assert "Max value: %d, scale: %f" % (mx, scale) in r.stdout
+        with open(o, "rb") as f:
+            assert f.read() == oracle.encode_pgm(gray)
+    bad = run(exe, "--channel", "100:20")          # no file name
+    assert bad.returncode == 0 and "Invalid channel" in bad.stdout and "Usage:" in bad.stdout
+
+
 def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path):
     buf = str(tmp_path / "seed.bin")
     r = run(exe, "--passes", "1", "--seed", "4242", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
