@@ -140,10 +140,18 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    # Rehearsal of the N > 1 path on a one-GPU box (never what the driver runs): every rank on cuda:0, gloo
+    # instead of RCCL (which refuses two ranks on one device).
+    same_device = os.environ.get("CUDABROT_AMD_BENCH_SAME_DEVICE") == "1"
+    if same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     dims = cb.FractalDimensions.make(W, H)
     it = cb.IterationControl(MAX_ITER, MIN_ITER)
@@ -267,7 +275,10 @@ def main():
     c_local = counters.clone()
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
-    reduce_histogram(hist, dst=0)
+    if same_device and world > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)   # gloo has no reduce() for device tensors
+    else:
+        reduce_histogram(hist, dst=0)
     torch.cuda.synchronize()
     cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
     loc = dict(zip(cnt.keys(), (int(v) for v in c_local.cpu().numpy().view(np.uint64))))
