@@ -33,7 +33,7 @@ W = H = 4096
 MAX_ITER, MIN_ITER = 20000, 20
 THREADS = 512 * 512
 SAMPLES_PER_PASS = 50
-PASSES_PER_STEP = 64
+PASSES_PER_STEP = int(os.environ.get("CUDABROT_AMD_BENCH_PASSES", "64"))   # reference passes fused into one launch
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (spec)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_ITERATION = 10         # 6 mul + 4 add/sub of cudabrot.cu:331-336

@@ -380,3 +380,21 @@ def test_burning_ship_variant_matches_the_reference_build_with_the_define(cb, or
         assert cnt[k] == rc[k], k
     plain, _ = oracle.render(w, h, 600, 20, t, passes, (-2.0, 2.0, -2.0, 1.0))
     assert not np.array_equal(got, plain)
+
+
+@pytest.mark.parametrize("name,w,h,max_iter,box", [
+    ("C3", 4096, 4096, 20000, BOX),                       # the bench workload: power-of-two deltas, one sort level
+    ("C2", 4096, 4096, 2000, BOX),
+    ("C5_plane", 20000, 15000, 8000, (-2.0, 2.0, -1.5, 1.5)),   # the colour recipe's canvas: division, two levels
+])
+def test_full_size_configs_against_the_oracle(cb, oracle, name, w, h, max_iter, box):
+    """BASELINE.json's shapes at full size, reference-sized passes (512 x 512 threads x 50 samples), through
+    the renderer (64-pass launches need not be filled: 3 passes): every pixel and every counter."""
+    t, passes = 512 * 512, 3
+    dims = cb.FractalDimensions.make(w, h, *box)
+    with cb.Renderer(dims, cb.IterationControl(max_iter, 20), n_threads=t) as r:
+        r.render_passes(passes)
+        got = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    ref, rc = oracle.render(w, h, max_iter, 20, t, passes, box, omp_threads=0)
+    assert_same((got, cnt), (ref, rc))

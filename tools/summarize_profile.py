@@ -19,7 +19,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
-KERNELS = ("draw_wave_kernel", "bin_count_kernel", "bin_scan_waves_kernel", "bin_scan_tiles_kernel",
+KERNELS = ("draw_wave_kernel", "bin_wave_regions_kernel", "bin_count_kernel", "bin_scan_rows_kernel", "bin_scan_keys_kernel",
            "bin_scatter_kernel", "bin_accumulate_kernel")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
@@ -74,7 +74,7 @@ out = {
     "pmc": pmc,
     "traffic_bytes_per_launch": {
         "draw_wave_kernel": traffic(["draw_wave_kernel"]),
-        "scatter_kernels": traffic(["bin_count_kernel", "bin_scan_waves_kernel", "bin_scan_tiles_kernel",
+        "scatter_kernels": traffic(["bin_wave_regions_kernel", "bin_count_kernel", "bin_scan_rows_kernel", "bin_scan_keys_kernel",
                                     "bin_scatter_kernel", "bin_accumulate_kernel"]),
         "note": "per launch of 64 fused passes; fabric-side (TCC_EA) bytes, Infinity-Cache hits included",
     },
