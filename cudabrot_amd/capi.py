@@ -23,6 +23,7 @@ CB_KERNEL_TIMED = 2
 CB_KERNEL_FULL_ITERATE = 3
 CB_TONE_AUTO, CB_TONE_LUT, CB_TONE_THRESHOLDS = 0, 1, 2
 CB_KERNEL_FLAG_BURNING_SHIP = 0x100
+CB_KERNEL_FLAG_DRAIN = 0x200
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -134,7 +134,7 @@ namespace {
 // Adds one launch (or, with passes == 0, the drain of the carried work) and its flush to the
 // renderer's streams.
 int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
-  const bool wave = (kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) != CB_KERNEL_SIMPLE;
+  const bool wave = (kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) != CB_KERNEL_SIMPLE;
   const bool deferred = r->d_workspace[0] && wave;
   const int k = r->next_workspace;
   if (deferred && r->flush_pending[k]) {
@@ -259,7 +259,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   if (!dims || !iterations || !d_hist || !d_states) return (int) hipErrorInvalidValue;
   if (dims->w <= 0 || dims->h <= 0) return (int) hipErrorInvalidValue;
   const bool ship = (kernel_variant & CB_KERNEL_FLAG_BURNING_SHIP) != 0;
-  const int base_variant = kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP;
+  const int base_variant = kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN);
   if (base_variant == CB_KERNEL_SIMPLE) {  // the baseline kernel: atomics, every launch complete
     d_workspace = nullptr;
     d_carry = nullptr;
@@ -267,6 +267,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   cb::DrawArgs a = make_args(dims, iterations, d_hist, d_states, n_threads, samples_per_thread,
                              d_counters, d_workspace, workspace_bytes, d_carry);
   a.burning_ship = ship ? 1 : 0;
+  if ((kernel_variant & CB_KERNEL_FLAG_DRAIN) && a.carry) a.drain = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
   switch (base_variant) {
@@ -304,7 +305,7 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
     return (int) hipErrorInvalidValue;
   }
   const bool ship = (kernel_variant & CB_KERNEL_FLAG_BURNING_SHIP) != 0;
-  const int base_variant = kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP;
+  const int base_variant = kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN);
   if (base_variant != CB_KERNEL_DEFAULT && base_variant != CB_KERNEL_FULL_ITERATE) {
     return (int) hipErrorInvalidValue;  // the wave-scheduled kernel only
   }
@@ -321,6 +322,7 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
   cb::DrawArgs a = make_args(dims, &hull, d_hist, d_states, n_threads, samples_per_thread, d_counters,
                              d_workspace, workspace_bytes, d_carry, n_channels);
   a.burning_ship = ship ? 1 : 0;
+  if ((kernel_variant & CB_KERNEL_FLAG_DRAIN) && a.carry) a.drain = 1;
   a.n_channels = n_channels;
   a.plane_pixels = (unsigned long long) dims->w * (unsigned long long) dims->h;
   for (int j = 0; j < n_channels; ++j) {
@@ -408,14 +410,14 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
     const long v = e ? atol(e) : 0;
     return (v >= 1 && v <= 4096) ? (uint32_t) v : kRendererPassesPerLaunch;
   }();
-  if ((kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") &&
+  if ((kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") &&
       !g_wave_dump) {
     const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
     if (hipMalloc(&g_wave_dump, bytes) != hipSuccess || hipMemset(g_wave_dump, 0, bytes) != hipSuccess) {
       g_wave_dump = nullptr;
     }
   }
-  if (!r->workspace_tried && (kernel_variant & ~CB_KERNEL_FLAG_BURNING_SHIP) != CB_KERNEL_SIMPLE &&
+  if (!r->workspace_tried && (kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) != CB_KERNEL_SIMPLE &&
       getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
     // scatter workspace for the largest launch this call makes; on any failure: direct atomics
     r->workspace_tried = 1;

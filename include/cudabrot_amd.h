@@ -93,6 +93,11 @@ typedef struct {
  * compile-time switch): |real|, |imag| before every step and no cardioid / bulb shortcut. */
 #define CB_KERNEL_FLAG_BURNING_SHIP 0x100
 
+/* OR-ed into a kernel variant, with a carry buffer: this launch also completes every orbit in flight
+ * (its own and the carried ones) instead of leaving them for the next launch -- the last launch of a
+ * render.  A launch with samples_per_thread = 0 does only that. */
+#define CB_KERNEL_FLAG_DRAIN 0x200
+
 /* RecomputePixelDeltas (cudabrot.cu:505-527).  Returns 1 and fills delta_* if the canvas is valid,
  * else 0 and, if msg is not NULL, *msg points at the reference's message for the failed check. */
 int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg);

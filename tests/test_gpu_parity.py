@@ -398,3 +398,32 @@ def test_full_size_configs_against_the_oracle(cb, oracle, name, w, h, max_iter, 
         cnt = r.read_counters().as_dict()
     ref, rc = oracle.render(w, h, max_iter, 20, t, passes, box, omp_threads=0)
     assert_same((got, cnt), (ref, rc))
+
+
+def test_drain_flag_completes_in_flight_orbits_in_the_last_launch(cb, oracle):
+    """CB_KERNEL_FLAG_DRAIN: with a carry buffer, the flagged launch draws its samples AND finishes every
+    orbit in flight -- no separate drain launch."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    w, h, t, launches = 384, 320, 8192, 3
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(1500, 20)
+    states = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(h * w, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    carry = torch.zeros(cb.carry_bytes(t), dtype=torch.uint8, device=dev)
+    ws_bytes = cb.scatter_workspace_bytes(dims, t, 100)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(1337, 0, t, states.data_ptr(), stream)
+    for n in range(launches):
+        flag = cb.CB_KERNEL_FLAG_DRAIN if n + 1 == launches else 0
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), t, 100, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT | flag, stream, ws.data_ptr(), ws_bytes, carry.data_ptr())
+        cb.flush_scatter(dims, hist.data_ptr(), t, ws.data_ptr(), ws_bytes, stream)
+    torch.cuda.synchronize()
+    c = counters.cpu().numpy().view(np.uint64)
+    cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in c)))
+    got = hist.cpu().numpy().view(np.uint64).reshape(h, w)
+    assert_same((got, cnt), oracle.render(w, h, 1500, 20, t, 2 * launches))
