@@ -65,9 +65,9 @@ namespace {
 constexpr int kWavesPerBlock = 4;
 constexpr int kOrbitsPerLane = 2;      // deep orbits a lane iterates side by side in the LONG stage
 constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
-constexpr int kQ1Cap = 128;            // MID survivors: (c, z)        (4 KiB per wave)
+constexpr int kQ1Cap = 96;             // MID survivors: (c, z)        (3 KiB per wave)
 constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
-constexpr int kQ1Low = 48;             // run MID while fewer deep orbits than this are queued
+constexpr int kQ1Low = 32;             // run MID while fewer deep orbits than this are queued
 constexpr int kQ1Exit = 8;             // LONG hands over to HEAD / MID below this many
 constexpr int kReplayMin = 32;         // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = 8;   // replay steps per asm burst
@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   "v_lshlrev_b32 " xk ", 1, %[t]\n\t"                    \
   "v_xor_b32 %[t], %[t], " xk "\n\t"                     \
   "v_xor_b32 " xk ", %[u], %[t]\n\t"                     \
-  "v_add3_u32 " out ", v125, " xk ", %[sc]\n\t"
+  "v_add3_u32 " out ", v109, " xk ", %[sc]\n\t"
 // C = fma(fma(hi, 2^32, lo), 2^-50, 2^-50 - 4) with lo = o1, hi = o2 >> 11 (0x41f00000: the high word
 // of 2^32 as the literal of a VOP2 fmac)
 #define CB_XW_COORD(c)                                   \
@@ -216,7 +216,7 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   "v_lshrrev_b32 %[o2], 11, %[o2]\n\t"                   \
   "v_cvt_f64_u32 %[f], %[o2]\n\t"                        \
   "v_fmac_f64_e32 " c ", 0x41f00000, %[f]\n\t"           \
-  "v_fma_f64 " c ", " c ", %[k2m50], v[126:127]\n\t"
+  "v_fma_f64 " c ", " c ", %[k2m50], v[110:111]\n\t"
 // Four outputs and both coordinates; X0..X4 = the registers of the logical words x0..x4.
 #define CB_HEAD_DRAW(X0, X1, X2, X3, X4)                 \
   CB_XW_DRAW(X0, X4, "%[o1]", "0x587c5")                 \
@@ -224,24 +224,24 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   CB_XW_COORD("%[cr]")                                   \
   CB_XW_DRAW(X2, X1, "%[o1]", "0x10974f")                \
   CB_XW_DRAW(X3, X2, "%[o2]", "0x161f14")                \
-  "v_add_u32 v125, %[sc], v125\n\t"                      \
+  "v_add_u32 v109, %[sc], v109\n\t"                      \
   CB_XW_COORD("%[ci]")
 static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u == 0x10974fu &&
                   4u * 362437u == 0x161f14u,
               "multiples of the Weyl increment (rocrand_xorwow.h:174)");
 
 // rot: logical word j lives in register v[120 + (j + rot) % 5].  In the kernels that use this block
-// the generator lives in v120..v125 (five words and the Weyl value) and v[126:127] holds the constant
-// 2^-50 - 4 for the whole launch: the kernel is compiled with a budget of 120 vector registers
+// the generator lives in v104..v109 (five words and the Weyl value) and v[110:111] holds the constant
+// 2^-50 - 4 for the whole launch: the kernel is compiled with a budget of 104 vector registers
 // (amdgpu_num_vgpr), so the compiler never touches them, and no copy in or out of the block is
 // needed (as operands the six words were copied to fresh registers and back on every pass).
 // One statement holds the text for the five rotations behind scalar branches; it also steps rot.
-#define CB_V_X0 "v120"
-#define CB_V_X1 "v121"
-#define CB_V_X2 "v122"
-#define CB_V_X3 "v123"
-#define CB_V_X4 "v124"
-#define CB_HEAD_RESERVED "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+#define CB_V_X0 "v104"
+#define CB_V_X1 "v105"
+#define CB_V_X2 "v106"
+#define CB_V_X3 "v107"
+#define CB_V_X4 "v108"
+#define CB_HEAD_RESERVED "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
 __device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci) {
   uint32_t t, u, o1, o2, sc, next;
   double f;
@@ -283,14 +283,14 @@ __device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci)
 // The reserved registers: load at the start of a launch (logical order, rot = 0) ...
 __device__ __forceinline__ void head_registers_load(const Xorwow &s) {
   asm volatile(
-      "v_mov_b32 v120, %[x0]\n\t"
-      "v_mov_b32 v121, %[x1]\n\t"
-      "v_mov_b32 v122, %[x2]\n\t"
-      "v_mov_b32 v123, %[x3]\n\t"
-      "v_mov_b32 v124, %[x4]\n\t"
-      "v_mov_b32 v125, %[d]\n\t"
-      "v_mov_b32 v126, 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
-      "v_mov_b32 v127, 0xc00fffff\n\t"
+      "v_mov_b32 v104, %[x0]\n\t"
+      "v_mov_b32 v105, %[x1]\n\t"
+      "v_mov_b32 v106, %[x2]\n\t"
+      "v_mov_b32 v107, %[x3]\n\t"
+      "v_mov_b32 v108, %[x4]\n\t"
+      "v_mov_b32 v109, %[d]\n\t"
+      "v_mov_b32 v110, 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
+      "v_mov_b32 v111, 0xc00fffff\n\t"
       :
       : [x0] "v"(s.x0), [x1] "v"(s.x1), [x2] "v"(s.x2), [x3] "v"(s.x3), [x4] "v"(s.x4), [d] "v"(s.d)
       : CB_HEAD_RESERVED);
@@ -299,12 +299,12 @@ __device__ __forceinline__ void head_registers_load(const Xorwow &s) {
 __device__ __forceinline__ Xorwow head_registers_read() {
   Xorwow s;
   asm volatile(
-      "v_mov_b32 %[x0], v120\n\t"
-      "v_mov_b32 %[x1], v121\n\t"
-      "v_mov_b32 %[x2], v122\n\t"
-      "v_mov_b32 %[x3], v123\n\t"
-      "v_mov_b32 %[x4], v124\n\t"
-      "v_mov_b32 %[d], v125\n\t"
+      "v_mov_b32 %[x0], v104\n\t"
+      "v_mov_b32 %[x1], v105\n\t"
+      "v_mov_b32 %[x2], v106\n\t"
+      "v_mov_b32 %[x3], v107\n\t"
+      "v_mov_b32 %[x4], v108\n\t"
+      "v_mov_b32 %[d], v109\n\t"
       : [x0] "=v"(s.x0), [x1] "=v"(s.x1), [x2] "=v"(s.x2), [x3] "=v"(s.x3), [x4] "=v"(s.x4),
         [d] "=v"(s.d));
   return s;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void head_test(unsigned long long valid, double cr, d
 // The lanes of `take` pop c from Q0 (ring slot (q0_head + lane) & 127 at LDS byte address q0_lds),
 // re-derive z after the four HEAD iterations (Q0 keeps only c; no escape is possible there, so no
 // compare), run n_steps more iterations under EXEC and push the survivors' (c, z) to Q1 (ring slot
-// (q1_tail + rank) & 127 at q1_lds; q1_ci, q1_r, q1_i follow at 1024-byte distances).  lane_steps:
+// (q1_tail + rank) mod 96 at q1_lds; q1_ci, q1_r, q1_i follow at 768-byte distances).  lane_steps:
 // the executed iterations of the n_steps window; alive: the survivors.
 #define CB_STEP_NOTEST                                \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
@@ -409,9 +409,9 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
                                          uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
                                          uint32_t q1_lds, unsigned long long &alive,
                                          uint32_t &lane_steps) {
-  static_assert(kQ0Cap == 128 && kQ1Cap == 128, "ring masks and plane distances below");
+  static_assert(kQ0Cap == 128 && kQ1Cap == 96, "ring mask, ring length and plane distances below");
   unsigned long long save;
-  uint32_t cnt, tmp, ctr, slot;
+  uint32_t cnt, tmp, ctr, slot, wr;
   double cr, ci, r, i, a;
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
@@ -441,15 +441,19 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_mov_b64 %[alive], exec\n\t"
       "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
       "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
-      "v_add_u32 %[slot], %[tail], %[slot]\n\t"
-      "v_and_b32 %[slot], 0x7f, %[slot]\n\t"
+      "v_add_u32 %[slot], %[tail], %[slot]\n\t"          // < 96 + 64
+      "v_subrev_u32 %[wr], 96, %[slot]\n\t"              // slot - 96: huge (unsigned) below 96
+      "v_min_u32 %[slot], %[slot], %[wr]\n\t"
       "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
-      "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"
-      "ds_write2st64_b64 %[slot], %[r], %[i] offset0:4 offset1:6\n\t"
+      "ds_write_b64 %[slot], %[cr]\n\t"
+      "ds_write_b64 %[slot], %[ci] offset:768\n\t"
+      "ds_write_b64 %[slot], %[r] offset:1536\n\t"
+      "ds_write_b64 %[slot], %[i] offset:2304\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "s_nop 4\n\t"
       : [alive] "=&s"(alive), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr),
-        [slot] "=&v"(slot), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i)
+        [slot] "=&v"(slot), [wr] "=&v"(wr), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r),
+        [i] "=&v"(i)
       : [take] "s"(take), [lph] "v"(lane_plus_head), [q0] "s"(q0_lds), [n] "s"(n_steps),
         [tail] "v"(q1_tail), [q1] "s"(q1_lds)
       : "vcc", "scc", "memory");
@@ -673,11 +677,13 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   hits = ch;
 }
 
-// ring index helper for the 192-entry Q2
+// ring index helpers for the 96-entry Q1 and the 192-entry Q2
+__device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
+//
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
 template <bool kTimed, bool kBinned, bool kFastHead>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(120)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(104)))
 draw_wave_kernel(DrawArgs a) {
   static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
   __shared__ WaveQueues queues[kWavesPerBlock];
@@ -704,7 +710,7 @@ draw_wave_kernel(DrawArgs a) {
 
   Xorwow rng = {0, 0, 0, 0, 0, 0};
   if (valid) rng = load_rng(a.states, a.n_threads, tid);
-  if constexpr (kFastHead) head_registers_load(rng);  // the generator lives in v120..v125 from here on
+  if constexpr (kFastHead) head_registers_load(rng);  // the generator lives in v104..v109 from here on
 
   // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t samples_left = a.samples_per_thread;
@@ -1002,7 +1008,7 @@ draw_wave_kernel(DrawArgs a) {
         unsigned long long alive;
         uint32_t steps;
         mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) mid_steps,
-                 (uint32_t) (q1_head + q1_count), q1_lds, alive, steps);
+                 (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
         q0_head = (q0_head + n) & (kQ0Cap - 1);
         q0_count -= n;
         n_iterate += steps;
@@ -1042,7 +1048,7 @@ draw_wave_kernel(DrawArgs a) {
       if (alive_mask != 0ull) {  // survivors of the mid stage
         if (long_steps > 0) {
           if (lane_in(alive_mask)) {
-            const int slot = (q1_head + q1_count + mask_prefix(alive_mask)) & (kQ1Cap - 1);
+            const int slot = q1_wrap(q1_wrap(q1_head + q1_count) + mask_prefix(alive_mask));
             q.q1_cr[slot] = o.cr;
             q.q1_ci[slot] = o.ci;
             q.q1_r[slot] = o.r;
@@ -1088,7 +1094,7 @@ draw_wave_kernel(DrawArgs a) {
           const int n = n_idle < q1_count ? n_idle : q1_count;
           const int rank = mask_prefix(idle_mask);
           if (l_rem[o] == 0 && rank < n) {
-            const int slot = (q1_head + rank) & (kQ1Cap - 1);
+            const int slot = q1_wrap(q1_head + rank);
             lo[o].cr = q.q1_cr[slot];
             lo[o].ci = q.q1_ci[slot];
             lo[o].r = q.q1_r[slot];
@@ -1097,7 +1103,7 @@ draw_wave_kernel(DrawArgs a) {
             seen_r[o] = lo[o].r;  // periodicity check: first saved point = the entry point
             seen_i[o] = lo[o].i;
           }
-          q1_head = (q1_head + n) & (kQ1Cap - 1);
+          q1_head = q1_wrap(q1_head + n);
           q1_count -= n;
         }
         full_mask[o] = __ballot(l_rem[o] >= kChunk);

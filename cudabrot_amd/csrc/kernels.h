@@ -119,7 +119,7 @@ struct DrawArgs {
 };
 
 constexpr uint32_t kCarryHeaderWords = 8;
-constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 128 + 2 * 192);  // = sizeof(WaveQueues) / 8
+constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 96 + 2 * 192);  // = sizeof(WaveQueues) / 8
 constexpr uint32_t kCarryLanePlanes = 19;
 constexpr uint32_t kCarryWordsPerWave = kCarryHeaderWords + kCarryQueueWords + kCarryLanePlanes * 64;
 
