@@ -69,8 +69,8 @@ constexpr int kQ1Cap = 96;             // MID survivors: (c, z)        (3 KiB pe
 constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
 constexpr int kQ1Low = 32;             // run MID while fewer deep orbits than this are queued
 constexpr int kQ1Exit = 8;             // LONG hands over to HEAD / MID below this many
-constexpr int kReplayMin = 32;         // suspend REPLAY below this many busy lanes (unless draining)
-constexpr uint32_t kReplayBurst = 8;   // replay steps per asm burst
+constexpr int kReplayMin = 40;         // suspend REPLAY below this many busy lanes (unless draining)
+constexpr uint32_t kReplayBurst = 16;  // replay steps per asm burst
 constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
 
 struct WaveQueues {
