@@ -427,3 +427,19 @@ def test_drain_flag_completes_in_flight_orbits_in_the_last_launch(cb, oracle):
     cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in c)))
     got = hist.cpu().numpy().view(np.uint64).reshape(h, w)
     assert_same((got, cnt), oracle.render(w, h, 1500, 20, t, 2 * launches))
+
+
+def test_burning_ship_goldens_on_the_gpu(cb, oracle):
+    """The committed RENDER_BURNING_SHIP goldens (tests/golden/burning_ship.json) through the wave kernel."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "burning_ship.json")) as f:
+        rows = json.load(f)["histograms"]
+    for g in rows:
+        hist, cnt = gpu_render(cb, g["w"], g["h"], g["max_iter"], g["min_iter"], g["threads"], g["passes"],
+                               tuple(g["box"]), variant=cb.CB_KERNEL_DEFAULT | cb.CB_KERNEL_FLAG_BURNING_SHIP)
+        assert cnt["status"] == 0 and cnt["samples"] == g["samples"], g["name"]
+        assert int(hist.sum()) == g["increments"] == cnt["increments"], g["name"]
+        assert int(hist.max()) == g["max"] and int((hist > 0).sum()) == g["nonzero"], g["name"]
+        assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"], g["name"]

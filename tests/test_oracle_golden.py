@@ -83,3 +83,24 @@ def test_degenerate_iteration_windows(oracle):
     for max_iter, min_iter in ((0, 20), (-3, 0), (50, 50), (50, 80)):
         hist, c = oracle.render(32, 32, max_iter, min_iter, 500, 1)
         assert hist.sum() == 0 and c["recorded"] == 0
+
+
+def _ship_goldens():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "burning_ship.json")) as f:
+        return json.load(f)["histograms"]
+
+
+@pytest.mark.parametrize("g", _ship_goldens(), ids=lambda g: g["name"])
+def test_burning_ship_goldens(oracle, g):
+    """tests/golden/burning_ship.json: the reference's lines built with -DRENDER_BURNING_SHIP (written by
+    tests/golden/make_goldens.py); pins the oracle's run-time switch where /root/reference is absent."""
+    hist, cnt = oracle.render(g["w"], g["h"], g["max_iter"], g["min_iter"], g["threads"], g["passes"], tuple(g["box"]),
+                              burning_ship=True)
+    assert cnt["samples"] == g["samples"] and cnt["rejected"] == 0
+    assert int(hist.sum()) == g["increments"] == cnt["increments"]
+    assert int(hist.max()) == g["max"]
+    assert int((hist > 0).sum()) == g["nonzero"]
+    assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"]
