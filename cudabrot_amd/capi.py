@@ -160,6 +160,7 @@ def _load():
         "cb_renderer_read_rng_states": (i32, [vp, vp]),
         "cb_renderer_write_rng_states": (i32, [vp, vp]),
         "cb_renderer_device_histogram": (vp, [vp]),
+        "cb_renderers_reduce": (i32, [C.POINTER(vp), i32]),
         "cb_renderer_destroy": (None, [vp]),
         "cb_set_grayscale_pixels": (None, [vp, i32, i32, C.c_double, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cb_save_image": (i32, [C.c_char_p, vp, i32, i32]),
@@ -184,7 +185,7 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
     "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states "
-    "cb_draw_buddhabrot_channels cb_flush_scatter_channels cb_renderer_create_channels cb_renderer_grayscale_plane"
+    "cb_draw_buddhabrot_channels cb_flush_scatter_channels cb_renderer_create_channels cb_renderer_grayscale_plane cb_renderers_reduce"
 ).split()
 
 
@@ -368,6 +369,12 @@ def flush_scatter_channels(dims, d_hist, n_channels, n_threads, d_workspace, wor
         lib.cb_flush_scatter_channels(C.byref(dims), d_hist, n_channels, n_threads, d_workspace, workspace_bytes, stream),
         "cb_flush_scatter_channels",
     )
+
+
+def renderers_reduce(renderers):
+    """renderers[0] += renderers[1:] (cb_renderers_reduce: RCCL across devices, an add kernel on one device)."""
+    arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+    _check(lib.cb_renderers_reduce(arr, len(renderers)), "cb_renderers_reduce")
 
 
 def tone_value(count, max_count, gamma):

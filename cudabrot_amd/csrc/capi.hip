@@ -1,6 +1,8 @@
 // capi.hip -- implementation of include/cudabrot_amd.h (the C ABI).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -192,6 +194,61 @@ int finish(cb_renderer *r) {
     if (rc) return rc;
   }
   return sync_streams(r);
+}
+
+__global__ void __launch_bounds__(256) add_histogram_kernel(unsigned long long *dst,
+                                                            const unsigned long long *src, size_t n) {
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] += src[i];
+}
+
+// ncclReduce of the renderers' histograms onto renderers[0] (one device each).  librccl is opened on
+// first use; the symbols are the ones rccl.h declares.
+int rccl_reduce_to_root(cb_renderer *const *renderers, int n, size_t count) {
+  static void *lib = nullptr;
+  static decltype(&ncclCommInitAll) comm_init_all = nullptr;
+  static decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  static decltype(&ncclGroupStart) group_start = nullptr;
+  static decltype(&ncclGroupEnd) group_end = nullptr;
+  static decltype(&ncclReduce) reduce = nullptr;
+  static std::mutex mutex;
+  std::lock_guard<std::mutex> lock(mutex);
+  if (!lib) {
+    lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return (int) hipErrorSharedObjectInitFailed;
+    comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(lib, "ncclCommInitAll"));
+    comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    group_start = reinterpret_cast<decltype(group_start)>(dlsym(lib, "ncclGroupStart"));
+    group_end = reinterpret_cast<decltype(group_end)>(dlsym(lib, "ncclGroupEnd"));
+    reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
+    if (!comm_init_all || !comm_destroy || !group_start || !group_end || !reduce) {
+      return (int) hipErrorSharedObjectSymbolNotFound;
+    }
+  }
+  std::vector<int> devices(n);
+  for (int k = 0; k < n; ++k) devices[k] = renderers[k]->device;
+  std::vector<ncclComm_t> comms(n);
+  if (comm_init_all(comms.data(), n, devices.data()) != ncclSuccess) return (int) hipErrorUnknown;
+  ncclResult_t nr = group_start();
+  for (int k = 0; k < n && nr == ncclSuccess; ++k) {
+    if (hipSetDevice(devices[k]) != hipSuccess) {
+      nr = ncclUnhandledCudaError;
+      break;
+    }
+    // in place on the root; u64 counters, integer sum: the result does not depend on the order
+    nr = reduce(renderers[k]->d_hist, renderers[k]->d_hist, count, ncclUint64, ncclSum, 0, comms[k],
+                renderers[k]->stream);
+  }
+  const ncclResult_t ne = group_end();
+  int rc = (nr == ncclSuccess && ne == ncclSuccess) ? 0 : (int) hipErrorUnknown;
+  for (int k = 0; k < n; ++k) {
+    (void) hipSetDevice(devices[k]);
+    const hipError_t e = hipStreamSynchronize(renderers[k]->stream);
+    if (e != hipSuccess && rc == 0) rc = (int) e;
+  }
+  for (int k = 0; k < n; ++k) (void) comm_destroy(comms[k]);
+  return rc;
 }
 
 }  // namespace
@@ -583,6 +640,50 @@ void cb_renderer_destroy(cb_renderer *r) {
   if (r->stream) (void) hipStreamDestroy(r->stream);
   if (r->flush_stream) (void) hipStreamDestroy(r->flush_stream);
   delete r;
+}
+
+// The one exchange of the multi-GPU path: renderers[0] += renderers[1..n).  Renderers on
+// n distinct devices: one ncclReduce(ncclUint64, ncclSum, root 0) over xGMI.  RCCL is loaded on first
+// use (dlopen), so single-GPU users of the library never touch it.  Renderers that all share one device
+// (a rehearsal of the sharded path on a one-GPU box): an add kernel.
+int cb_renderers_reduce(cb_renderer *const *renderers, int n) {
+  if (!renderers || n < 1) return (int) hipErrorInvalidValue;
+  for (int k = 0; k < n; ++k) {
+    cb_renderer *r = renderers[k];
+    if (!r || r->dims.w != renderers[0]->dims.w || r->dims.h != renderers[0]->dims.h ||
+        r->n_channels != renderers[0]->n_channels) {
+      return (int) hipErrorInvalidValue;
+    }
+    CB_TRY(hipSetDevice(r->device));
+    const int rc = finish(r);
+    if (rc) return rc;
+  }
+  cb_renderer *root = renderers[0];
+  const size_t count = (size_t) root->dims.w * (size_t) root->dims.h * (size_t) (root->n_channels ? root->n_channels : 1);
+  if (n == 1) {
+    // CUDABROT_AMD_FORCE_RCCL=1 (test knob): a reduce over one rank, to exercise the RCCL calls where
+    // only one device exists
+    return getenv("CUDABROT_AMD_FORCE_RCCL") ? rccl_reduce_to_root(renderers, 1, count) : 0;
+  }
+  bool same = true, distinct = true;
+  for (int a = 0; a < n; ++a) {
+    if (renderers[a]->device != root->device) same = false;
+    for (int b = a + 1; b < n; ++b) {
+      if (renderers[a]->device == renderers[b]->device) distinct = false;
+    }
+  }
+  if (same) {
+    CB_TRY(hipSetDevice(root->device));
+    for (int k = 1; k < n; ++k) {
+      hipLaunchKernelGGL(add_histogram_kernel, dim3(256 * 8), dim3(256), 0, root->stream,
+                         reinterpret_cast<unsigned long long *>(root->d_hist),
+                         reinterpret_cast<const unsigned long long *>(renderers[k]->d_hist), count);
+      CB_TRY(hipGetLastError());
+    }
+    return (int) hipStreamSynchronize(root->stream);
+  }
+  if (!distinct) return (int) hipErrorInvalidValue;
+  return rccl_reduce_to_root(renderers, n, count);
 }
 
 }  // extern "C"

@@ -12,7 +12,7 @@
 //  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
 //    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
 //  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
-//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship, --channel MAX:MIN:FILE.
+//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship, --channel MAX:MIN:FILE, --gpus N.
 #include <errno.h>
 #include <signal.h>
 #include <stdint.h>
@@ -23,6 +23,7 @@
 
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/cudabrot_amd.h"
@@ -43,6 +44,7 @@ struct Settings {
   int kernel_variant = CB_KERNEL_DEFAULT;           // --kernel (extension)
   bool print_stats = false;                         // --stats  (extension)
   bool burning_ship = false;                        // --burning-ship (extension; cudabrot.cu:15-17)
+  int gpus = 1;                                     // --gpus N (extension): devices -d .. -d + N - 1
   // --channel MAX:MIN:FILE (extension, repeatable): fused multi-channel render, one image per window
   int n_channels = 0;
   cb_iteration_control channel_window[CB_MAX_CHANNELS] = {};
@@ -173,6 +175,8 @@ const std::vector<Flag> &flag_table() {
          s.channel_file[s.n_channels] = t + used;
          s.n_channels++;
        }},
+      {"--gpus", Value::kInt, nullptr, false,
+       [](Settings &s, long i, double, const char *) { s.gpus = (i < 1) ? 1 : (i > 64 ? 64 : (int) i); }},
       {"--burning-ship", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.burning_ship = true; }},
       {"--seed", Value::kInt, nullptr, false,
@@ -300,7 +304,10 @@ class Run {
 
  private:
   Settings cfg_;
-  cb_renderer *renderer_ = nullptr;
+  cb_renderer *renderer_ = nullptr;      // rank 0: loads, receives the reduced histogram, tone-maps, saves
+  // --gpus N: ranks 1..N-1, one per further device, subsequences [r T, (r+1) T) of the
+  // same seed; their histograms are summed onto rank 0 once, after the pass loop (cb_renderers_reduce)
+  std::vector<cb_renderer *> peers_;
   cb_pixel *counts_ = nullptr;   // host mirror of the histogram (only with -s or --tonemap host)
   uint16_t *gray_ = nullptr;
   bool gray_is_big_endian_ = false;
@@ -312,6 +319,8 @@ class Run {
   uint64_t buffer_bytes() const { return planes() * pixel_count() * sizeof(cb_pixel); }
 
   void release() {  // cudabrot.cu:112-119
+    for (cb_renderer *p : peers_) cb_renderer_destroy(p);
+    peers_.clear();
     cb_renderer_destroy(renderer_);
     renderer_ = nullptr;
     free(gray_);
@@ -340,12 +349,24 @@ class Run {
     float cpu_mib = (float) (buffer_bytes() + pixel_count() * sizeof(uint16_t));
     cpu_mib /= (1024.0 * 1024.0);
     printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
-    if (cfg_.n_channels > 0) {
-      CB_CHECK(cb_renderer_create_channels(&renderer_, cfg_.device, &cfg_.canvas, cfg_.channel_window,
-                                           cfg_.n_channels, cfg_.seed, 0, CB_DEFAULT_THREADS));
-    } else {
-      CB_CHECK(cb_renderer_create(&renderer_, cfg_.device, &cfg_.canvas, &cfg_.iterations,
-                                  cfg_.seed, 0, CB_DEFAULT_THREADS));
+    // CUDABROT_AMD_FAKE_GPUS=1: every rank on device -d (rehearsal of --gpus on a one-GPU box)
+    const bool fake = getenv("CUDABROT_AMD_FAKE_GPUS") != nullptr;
+    for (int r = 0; r < cfg_.gpus; ++r) {
+      cb_renderer *one = nullptr;
+      const int device = cfg_.device + (fake ? 0 : r);
+      const uint64_t first = (uint64_t) r * CB_DEFAULT_THREADS;
+      if (cfg_.n_channels > 0) {
+        CB_CHECK(cb_renderer_create_channels(&one, device, &cfg_.canvas, cfg_.channel_window, cfg_.n_channels,
+                                             cfg_.seed, first, CB_DEFAULT_THREADS));
+      } else {
+        CB_CHECK(cb_renderer_create(&one, device, &cfg_.canvas, &cfg_.iterations, cfg_.seed, first,
+                                    CB_DEFAULT_THREADS));
+      }
+      if (r == 0) {
+        renderer_ = one;
+      } else {
+        peers_.push_back(one);
+      }
     }
     if (need_host_counts()) {
       counts_ = (cb_pixel *) calloc(1, buffer_bytes());
@@ -441,6 +462,10 @@ class Run {
   void load_rng_state() {
     const char *path = cfg_.rng_state_file;
     if (!path) return;
+    if (cfg_.gpus > 1) {
+      printf("--rng-state keeps one device's generator: not available with --gpus %d.\n", cfg_.gpus);
+      die();
+    }
     FILE *f = fopen(path, "rb");
     printf("Loading generator state from %s.\n", path);
     if (!f) {
@@ -508,31 +533,47 @@ class Run {
       }
     }
     fflush(stdout);
-    const double launch_seconds = 0.2;
     const double t0 = wall_seconds();
-    long done = 0, next = 1;
-    while (!g_quit_requested) {
-      if (!by_clock) {
-        if (done >= cfg_.fixed_passes) break;
-        next = cfg_.fixed_passes - done;
-        if (next > 256) next = 256;
+    const int variant = cfg_.kernel_variant | (cfg_.burning_ship ? CB_KERNEL_FLAG_BURNING_SHIP : 0);
+    // the pass loop of one rank; every rank follows the same clock / pass budget
+    auto pass_loop = [&](cb_renderer *r) -> long {
+      const double launch_seconds = 0.2;
+      long done = 0, next = 1;
+      while (!g_quit_requested) {
+        if (!by_clock) {
+          if (done >= cfg_.fixed_passes) break;
+          next = cfg_.fixed_passes - done;
+          if (next > 256) next = 256;
+        }
+        CB_CHECK(cb_renderer_render_passes(r, (uint32_t) next, variant));
+        done += next;
+        if (!by_clock) continue;
+        const double elapsed = wall_seconds() - t0;
+        if (cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run) break;
+        double budget = launch_seconds;
+        if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < budget) {
+          budget = cfg_.seconds_to_run - elapsed;
+        }
+        const double per_pass = elapsed / (double) done;
+        next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
+        if (next < 1) next = 1;
+        if (next > 4096) next = 4096;
+        if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
       }
-      CB_CHECK(cb_renderer_render_passes(
-          renderer_, (uint32_t) next,
-          cfg_.kernel_variant | (cfg_.burning_ship ? CB_KERNEL_FLAG_BURNING_SHIP : 0)));
-      done += next;
-      if (!by_clock) continue;
-      const double elapsed = wall_seconds() - t0;
-      if (cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run) break;
-      double budget = launch_seconds;
-      if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < budget) {
-        budget = cfg_.seconds_to_run - elapsed;
-      }
-      const double per_pass = elapsed / (double) done;
-      next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
-      if (next < 1) next = 1;
-      if (next > 4096) next = 4096;
-      if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
+      return done;
+    };
+    std::vector<long> peer_done(peers_.size(), 0);
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < peers_.size(); ++k) {
+      workers.emplace_back([&, k] { peer_done[k] = pass_loop(peers_[k]); });
+    }
+    long done = pass_loop(renderer_);
+    for (std::thread &w : workers) w.join();
+    for (long d : peer_done) done += d;
+    if (!peers_.empty()) {  // the one exchange of the path: sum the shards onto rank 0
+      std::vector<cb_renderer *> all(1, renderer_);
+      all.insert(all.end(), peers_.begin(), peers_.end());
+      CB_CHECK(cb_renderers_reduce(all.data(), (int) all.size()));
     }
     if (need_host_counts()) {
       CB_CHECK(cb_renderer_read_histogram(renderer_, counts_));  // cudabrot.cu:496-497
@@ -575,6 +616,20 @@ class Run {
   void print_stats() {
     cb_counters c;
     CB_CHECK(cb_renderer_read_counters(renderer_, &c));
+    for (cb_renderer *p : peers_) {  // workload counters add up over the ranks (the clocks are rank 0's)
+      cb_counters o;
+      CB_CHECK(cb_renderer_read_counters(p, &o));
+      c.samples += o.samples;
+      c.rejected += o.rejected;
+      c.never_escaped += o.never_escaped;
+      c.too_fast += o.too_fast;
+      c.recorded += o.recorded;
+      c.iterate_steps += o.iterate_steps;
+      c.replay_steps += o.replay_steps;
+      c.increments += o.increments;
+      c.skipped_steps += o.skipped_steps;
+      c.status |= o.status;
+    }
     fprintf(stderr,
             "{\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
             "\"recorded\": %llu, \"iterate_steps\": %llu, \"replay_steps\": %llu, "

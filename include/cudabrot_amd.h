@@ -205,6 +205,12 @@ int cb_renderer_read_rng_states(cb_renderer *r, void *host_out);
 int cb_renderer_write_rng_states(cb_renderer *r, const void *host_in);
 /* Device pointer of the histogram, for a caller-side RCCL reduce. */
 cb_pixel *cb_renderer_device_histogram(cb_renderer *r);
+/* The one exchange of the multi-GPU path (the reference has no multi-GPU code): rank r
+ * renders with first_subsequence = r * n_threads on its own device, then renderers[0] += renderers[1..n)
+ * -- one ncclReduce(ncclUint64, ncclSum, root 0) over xGMI when the renderers sit on n distinct devices
+ * (RCCL is loaded on first use), an add kernel when they all share one (rehearsal on a one-GPU box).
+ * Finishes carried work of every renderer first. */
+int cb_renderers_reduce(cb_renderer *const *renderers, int n);
 /* CleanupGlobals (cudabrot.cu:112-119). */
 void cb_renderer_destroy(cb_renderer *r);
 

@@ -124,6 +124,23 @@ def test_channel_flags_render_the_colour_recipe_in_one_run(exe, oracle, tmp_path
     assert bad.returncode == 0 and "Invalid channel" in bad.stdout and "Usage:" in bad.stdout
 
 
+def test_gpus_flag_shards_the_subsequences_and_sums_once(exe, oracle, tmp_path):
+    """--gpus N (extension): rank r renders subsequences [r T, (r+1) T) on its own device and
+    the histograms are summed onto rank 0 once.  CUDABROT_AMD_FAKE_GPUS=1 puts every rank on device 0 (this
+    box has one GPU): 3 "GPUs" x 2 passes == one run of 3 T threads x 2 passes."""
+    buf = str(tmp_path / "multi.bin")
+    env = dict(os.environ, CUDABROT_AMD_FAKE_GPUS="1")
+    r = run(exe, "--gpus", "3", "--passes", "2", "--stats", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull,
+            "-s", buf, env=env)
+    assert r.returncode == 0, r.stdout
+    assert re.search(r"^6 Buddhabrot passes took", r.stdout, re.M)          # 3 ranks x 2 passes
+    hist, cnt = oracle.render(300, 200, 200, 20, 3 * T, 2, omp_threads=0)
+    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+    import json
+    stats = json.loads(r.stderr.strip().splitlines()[-1])
+    assert stats["samples"] == cnt["samples"] and stats["increments"] == cnt["increments"] and stats["status"] == 0
+
+
 def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path):
     buf = str(tmp_path / "seed.bin")
     r = run(exe, "--passes", "1", "--seed", "4242", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)

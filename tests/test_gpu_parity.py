@@ -443,3 +443,40 @@ def test_burning_ship_goldens_on_the_gpu(cb, oracle):
         assert int(hist.sum()) == g["increments"] == cnt["increments"], g["name"]
         assert int(hist.max()) == g["max"] and int((hist > 0).sum()) == g["nonzero"], g["name"]
         assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"], g["name"]
+
+
+def test_renderers_reduce_sums_the_shards_onto_the_first(cb, oracle):
+    """cb_renderers_reduce, the one exchange of the multi-GPU path.  Here all shards sit on
+    one device (the add-kernel form; across devices the same call is one ncclReduce): three shards of T
+    threads == one run of 3 T threads."""
+    w, h, t, passes = 300, 200, 4096, 3
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(500, 20)
+    shards = [cb.Renderer(dims, it, first_subsequence=k * t, n_threads=t) for k in range(3)]
+    try:
+        for r in shards:
+            r.render_passes(passes)
+        cb.renderers_reduce(shards)            # finishes the carried orbits of every shard first
+        got = shards[0].read_histogram()
+        untouched = shards[1].read_histogram()
+    finally:
+        for r in shards:
+            r.close()
+    whole, _ = oracle.render(w, h, 500, 20, 3 * t, passes)
+    assert np.array_equal(got, whole)
+    second, _ = oracle.render(w, h, 500, 20, t, passes, first_subsequence=t)
+    assert np.array_equal(untouched, second)
+
+
+def test_rccl_reduce_calls_on_one_rank(cb, oracle, monkeypatch):
+    """The ncclReduce form of cb_renderers_reduce needs one device per rank; with a single rank
+    (CUDABROT_AMD_FORCE_RCCL=1) the same code path -- dlopen of librccl, ncclCommInitAll, grouped
+    ncclReduce(ncclUint64, ncclSum), stream sync, destroy -- runs on this box and must leave the histogram as it is."""
+    monkeypatch.setenv("CUDABROT_AMD_FORCE_RCCL", "1")
+    dims = cb.FractalDimensions.make(256, 192)
+    with cb.Renderer(dims, cb.IterationControl(300, 20), n_threads=4096) as r:
+        r.render_passes(2)
+        cb.renderers_reduce([r])
+        got = r.read_histogram()
+    ref, _ = oracle.render(256, 192, 300, 20, 4096, 2)
+    assert np.array_equal(got, ref)
