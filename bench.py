@@ -113,6 +113,17 @@ def reference_gpu(seconds=6):
             pass
 
 
+def baseline_metric():
+    """BASELINE.json's metric, verbatim (`value` is its Msamples/sec part: samples drawn per second of the pass
+    loop; the escaping points/s and the HBM GB/s parts are `escaping_points_per_sec` and
+    `roofline_scatter`)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "Msamples/sec (escaping points) + HBM GB/s, 4096x4096 max_iter=20000, 1/2/4/8 GPU"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,7 +316,7 @@ def main():
             scatter_ms, scatter_incr = avg_ms, incr_per_launch
         scatter_gbps = scatter_incr * BYTES_PER_INCREMENT / (scatter_ms * 1e-3) / 1e9
         line = {
-            "metric": "Msamples/sec",
+            "metric": baseline_metric(),
             "value": round(samples / elapsed / 1e6, 3),
             "unit": "Msamples/s",
             "n_gpus": world,
