@@ -275,7 +275,7 @@ __device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci)
       "s_cselect_b32 %[next], %[sc], %[next]\n\t"
       : [cr] "=&v"(cr), [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1),
         [o2] "=&v"(o2), [f] "=&v"(f), [sc] "=&s"(sc), [next] "=&s"(next)
-      : [rot] "s"(rot), [k2m50] "s"(0x1p-50)
+      : [rot] "s"(__builtin_amdgcn_readfirstlane(rot)), [k2m50] "s"(0x1p-50)
       : "scc", CB_HEAD_RESERVED);
   rot = next;
 }
@@ -528,6 +528,139 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   lane_steps = cnt;
 }
 
+// ---- LONG bookkeeping around a chunk, one orbit slot at a time ---------------------------------------
+//
+// long_refill: the idle lanes (l_rem == 0) of the slot take (c, z) from Q1 -- ring slot
+// (q1_head + rank) mod 96 at LDS byte address q1_lds, planes 768 bytes apart -- with l_rem =
+// long_steps and the periodicity check's saved point = the entry point.  `taken`: orbits popped;
+// `full`: lanes with a whole chunk ahead; `tail`: lanes left with exactly the last, shorter chunk
+// (l_rem == tail_steps; pass ~0 when there is none).
+__device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &seen_i, int &l_rem,
+                                            uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
+                                            uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
+                                            unsigned long long &full, unsigned long long &tail) {
+  static_assert(kQ1Cap == 96 && kChunk == 32, "ring length, plane distances and chunk length below");
+  unsigned long long save;
+  uint32_t n, rank, slot, t;
+  asm volatile(
+      "v_cmp_eq_u32_e32 vcc, 0, %[lrem]\n\t"            // idle lanes
+      "s_bcnt1_i32_b64 %[n], vcc\n\t"
+      "s_min_u32 %[n], %[n], %[qc]\n\t"
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "v_mbcnt_lo_u32_b32 %[rank], vcc_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[rank], vcc_hi, %[rank]\n\t"
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "v_cmpx_gt_u32_e32 vcc, %[n], %[rank]\n\t"         // the first n idle lanes
+      "v_add_u32 %[slot], %[head], %[rank]\n\t"          // < 96 + 64
+      "v_subrev_u32 %[t], 96, %[slot]\n\t"
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
+      "ds_read_b64 %[cr], %[slot]\n\t"
+      "ds_read_b64 %[ci], %[slot] offset:768\n\t"
+      "ds_read_b64 %[r], %[slot] offset:1536\n\t"
+      "ds_read_b64 %[i], %[slot] offset:2304\n\t"
+      "ds_read_b64 %[sr], %[slot] offset:1536\n\t"      // the saved point of the periodicity check = z
+      "ds_read_b64 %[si], %[slot] offset:2304\n\t"
+      "v_mov_b32 %[lrem], %[ls]\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "1:\n\t"
+      "v_cmp_le_u32_e64 %[full], 32, %[lrem]\n\t"
+      "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
+        [lrem] "+v"(l_rem), [n] "=&s"(n), [full] "=&s"(full), [tail] "=&s"(tail), [save] "=&s"(save),
+        [rank] "=&v"(rank), [slot] "=&v"(slot), [t] "=&v"(t)
+      : [qc] "s"(q1_count), [head] "s"(q1_head), [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value)
+      : "vcc", "scc", "memory");
+  taken = n;
+}
+
+#define CB_RETIRE_SURVIVORS                                \
+      "v_subrev_u32 %[lrem], 32, %[lrem]\n\t"            \
+      "v_cmp_eq_u32_e64 %[ended], 0, %[lrem]\n\t"        \
+      "s_cmp_eq_u32 %[chkf], 0\n\t"                      \
+      "s_cbranch_scc1 2f\n\t"                            \
+      "v_cmp_eq_u64_e32 vcc, %[r], %[sr]\n\t"            \
+      "s_mov_b64 %[per], vcc\n\t"                        \
+      "v_cmp_eq_u64_e32 vcc, %[i], %[si]\n\t"            \
+      "s_and_b64 %[per], %[per], vcc\n\t"                \
+      "s_andn2_b64 %[per], %[per], %[ended]\n\t"         \
+      "s_cmp_eq_u64 %[per], 0\n\t"                       \
+      "s_cbranch_scc1 2f\n\t"                            \
+      "s_mov_b64 exec, %[per]\n\t"                       \
+      "v_add_co_u32 %[klo], vcc, %[klo], %[lrem]\n\t"    \
+      "v_addc_co_u32 %[khi], vcc, 0, %[khi], vcc\n\t"    \
+      "v_mov_b32 %[lrem], 0\n\t"                         \
+      "s_andn2_b64 exec, %[ran], %[esc]\n\t"             \
+      "2:\n\t"                                           \
+      "s_andn2_b64 exec, exec, %[per]\n\t"
+#define CB_RETIRE_TAIL                                     \
+      "v_sub_u32 %[t], %[ls], %[lrem]\n\t"               \
+      "v_lshrrev_b32 %[t], 5, %[t]\n\t"                  \
+      "v_add_u32 %[slot], -1, %[t]\n\t"                  \
+      "v_and_b32 %[slot], %[slot], %[t]\n\t"             \
+      "v_cmpx_eq_u32_e32 vcc, 0, %[slot]\n\t"            \
+      "v_mov_b64 %[sr], %[r]\n\t"                        \
+      "v_mov_b64 %[si], %[i]\n\t"                        \
+      "3:\n\t"                                           \
+      "s_mov_b64 exec, %[save]\n\t"                      \
+      "s_nop 4\n\t"
+#define CB_RETIRE_ESCAPED                                  \
+      "s_mov_b64 %[save], exec\n\t"  \
+      "s_mov_b64 %[push], 0\n\t"  \
+      "s_mov_b64 %[ended], 0\n\t"  \
+      "s_mov_b64 %[per], 0\n\t"  \
+      "s_mov_b64 exec, %[esc]\n\t"  \
+      "s_cbranch_execz 1f\n\t"  \
+      "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem]\n\t"  \
+      "v_mov_b32 %[lrem], 0\n\t"  \
+      "s_mov_b64 %[push], vcc\n\t"  \
+      "s_mov_b64 exec, vcc\n\t"  \
+      "s_cbranch_execz 1f\n\t"  \
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"  \
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"  \
+      "v_add_u32 %[slot], %[tail2], %[slot]\n\t"  \
+      "v_subrev_u32 %[t], 192, %[slot]\n\t"  \
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"  \
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"  \
+      "ds_write_b64 %[slot], %[cr]\n\t"  \
+      "ds_write_b64 %[slot], %[ci] offset:1536\n\t"  \
+      "1:\n\t"  \
+      "s_andn2_b64 exec, %[ran], %[esc]\n\t"  \
+      "s_cbranch_execz 3f\n\t"
+
+// long_retire: after a chunk on the lanes of `ran`, of which `esc` escaped.
+//   escaped lanes    l_rem = 0; those whose chunk lies at or above min_iter (l_rem <= accept_rem, the
+//                    chunk being on one side of min_iter, cudabrot.cu:407-408) push c to Q2 -- ring slot
+//                    (q2_tail + rank) mod 192 at q2_lds, q2_ci 1536 bytes on: `push`
+//   the others       l_rem -= 32; `ended`: reached max_iter (IterateMandelbrot returns max,
+//                    cudabrot.cu:339); `periodic` (check_periodic != 0 only): z is bit for bit the saved
+//                    point, so the orbit repeats for ever and can never escape -- retired with the
+//                    remaining iterations added to skip (two 32-bit halves); else Brent's schedule:
+//                    re-save z when the number of chunks done is a power of two
+__device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, double &seen_i, int &l_rem,
+                                            uint32_t &skip_lo, uint32_t &skip_hi, unsigned long long ran,
+                                            unsigned long long esc, int accept_rem, uint32_t long_steps,
+                                            uint32_t check_periodic, uint32_t q2_tail, uint32_t q2_lds,
+                                            unsigned long long &push, unsigned long long &ended,
+                                            unsigned long long &periodic) {
+  static_assert(kQ2Cap == 192 && kChunk == 32, "ring length, plane distance and chunk length below");
+  unsigned long long save;
+  uint32_t slot, t;
+#define CB_RETIRE_OPERANDS                                                                                   \
+  : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),      \
+    [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic), [save] "=&s"(save), [slot] "=&v"(slot), \
+    [t] "=&v"(t)                                                                                             \
+  : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),       \
+    [chkf] "s"(check_periodic),                                                                              \
+    [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)                             \
+  : "vcc", "scc", "memory"
+  asm volatile(CB_RETIRE_ESCAPED CB_RETIRE_SURVIVORS CB_RETIRE_TAIL CB_RETIRE_OPERANDS);
+#undef CB_RETIRE_OPERANDS
+}
+
 // ---- REPLAY burst: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream --------------------
 //
 // One step for the lanes of `act` (EXEC), in the order of the reference's loop body, on doubled
@@ -737,6 +870,8 @@ draw_wave_kernel(DrawArgs a) {
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
   const uint32_t q1_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q1_cr[0])));
+  const uint32_t q2_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q2_cr[0])));
   // MID as one asm block (mid_pass) under the usual split: HEAD did four iterations, every escape inside
   // MID is too fast (the stage ends at or before min_iter) and survivors have iterations left
   const bool fast_mid = kFastHead && (min_iter >= long_start) && (long_steps > 0);
@@ -744,7 +879,13 @@ draw_wave_kernel(DrawArgs a) {
   Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
   int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
-  unsigned long long skipped_steps = 0;  // per lane: iterations the periodicity check made unnecessary
+  uint32_t skip_lo = 0, skip_hi = 0;  // per lane, 64 bits: iterations the periodicity check made unnecessary
+  // (wave-uniform values that feed "s" operands of the asm blocks go through readfirstlane once, here)
+  const uint32_t tail_value =  // l_rem of a lane left with the tail chunk
+      __builtin_amdgcn_readfirstlane(tail_steps ? (uint32_t) tail_steps : ~0u);
+  const int accept_rem = (int) __builtin_amdgcn_readfirstlane((uint32_t) (max_iter - min_iter));
+  const uint32_t check_flag = __builtin_amdgcn_readfirstlane((uint32_t) a.check_periodic);
+  const uint32_t long_steps_u = __builtin_amdgcn_readfirstlane((uint32_t) long_steps);
   // REPLAY lane state
   Orbit po = {0, 0, 0, 0};
   bool p_act = false;
@@ -1085,30 +1226,15 @@ draw_wave_kernel(DrawArgs a) {
         }
       }
       ++long_chunks;
-      unsigned long long full_mask[kOrbitsPerLane], tail_mask[kOrbitsPerLane], esc[kOrbitsPerLane];
+      unsigned long long full_mask[kOrbitsPerLane], tail_mask[kOrbitsPerLane];
 #pragma unroll
-      for (int o = 0; o < kOrbitsPerLane; ++o) {  // refill idle orbit slots from Q1
-        const unsigned long long idle_mask = __ballot(l_rem[o] == 0);
-        if (idle_mask != 0ull && q1_count > 0) {
-          const int n_idle = __popcll(idle_mask);
-          const int n = n_idle < q1_count ? n_idle : q1_count;
-          const int rank = mask_prefix(idle_mask);
-          if (l_rem[o] == 0 && rank < n) {
-            const int slot = q1_wrap(q1_head + rank);
-            lo[o].cr = q.q1_cr[slot];
-            lo[o].ci = q.q1_ci[slot];
-            lo[o].r = q.q1_r[slot];
-            lo[o].i = q.q1_i[slot];
-            l_rem[o] = long_steps;
-            seen_r[o] = lo[o].r;  // periodicity check: first saved point = the entry point
-            seen_i[o] = lo[o].i;
-          }
-          q1_head = q1_wrap(q1_head + n);
-          q1_count -= n;
-        }
-        full_mask[o] = __ballot(l_rem[o] >= kChunk);
-        tail_mask[o] = (tail_steps != 0) ? __ballot(l_rem[o] > 0 && l_rem[o] < kChunk) : 0ull;
-        esc[o] = 0ull;
+      for (int o = 0; o < kOrbitsPerLane; ++o) {  // refill idle orbit slots from Q1 (asm: long_refill)
+        uint32_t taken = 0;
+        long_refill(lo[o], seen_r[o], seen_i[o], l_rem[o], __builtin_amdgcn_readfirstlane((uint32_t) q1_head),
+                    __builtin_amdgcn_readfirstlane((uint32_t) q1_count), q1_lds, long_steps_u, tail_value, taken,
+                    full_mask[o], tail_mask[o]);
+        q1_head = q1_wrap(q1_head + (int) taken);
+        q1_count -= (int) taken;
       }
       if ((full_mask[0] | full_mask[1] | tail_mask[0] | tail_mask[1]) == 0ull) break;
 
@@ -1117,74 +1243,56 @@ draw_wave_kernel(DrawArgs a) {
 #pragma unroll
         for (int o = 0; o < kOrbitsPerLane; ++o) {
           if (tail_mask[o] != 0ull) {  // last, shorter chunk of these orbits: exactly tail_steps iterations
-            esc[o] = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o], steps);
+            const unsigned long long esc_t = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o], steps);
             n_iterate += steps;
-            n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc[o]);
+            n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc_t);  // reached max_iter (cudabrot.cu:339)
+            // the tail chunk lies on one side of min_iter like every chunk (cudabrot.cu:407-408)
+            const bool push = lane_in(esc_t) && (max_iter - l_rem[o] >= min_iter);
+            const unsigned long long push_mask = __ballot(push);
+            n_too_fast += (unsigned long long) __popcll(esc_t & ~push_mask);
+            if (lane_in(tail_mask[o])) l_rem[o] = 0;
+            if (push_mask != 0ull) {
+              if (push) {
+                const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(push_mask));
+                q.q2_cr[slot] = lo[o].cr;
+                q.q2_ci[slot] = lo[o].ci;
+              }
+              q2_count += __popcll(push_mask);
+              if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+            }
           }
         }
       }
       if ((full_mask[0] | full_mask[1]) != 0ull) {
-        unsigned long long e0, e1;
-        iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], e0, e1, steps);
-        esc[0] |= e0;
-        esc[1] |= e1;
+        unsigned long long esc[kOrbitsPerLane];
+        iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], steps);
         n_iterate += steps;
         if (kTimed) {
           dbg_chunks++;
           dbg_slots += (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
         }
-      }
-      // Bookkeeping.  An orbit's chunk covered escape indices [k_lo, k_lo + chunk length) with
-      // k_lo = max_iter - l_rem; min_iter - long_start is a multiple of kChunk, so the whole chunk is
-      // on one side of min_iter (cudabrot.cu:407-408).
+        // Bookkeeping (asm: long_retire).  An orbit's chunk covered escape indices [k_lo, k_lo + 32)
+        // with k_lo = max_iter - l_rem; min_iter - long_start is a multiple of kChunk, so the whole chunk
+        // is on one side of min_iter (cudabrot.cu:407-408): escapes with l_rem <= max_iter - min_iter are
+        // accepted.  Exact-periodicity early-out: if z is bit for bit a value this
+        // orbit held at an earlier chunk boundary, the (deterministic) orbit repeats that stretch for
+        // ever and every point of it passed the escape test: the sample can never escape, so
+        // IterateMandelbrot would return max_iterations -- the same outcome, without executing the
+        // remaining iterations.  Brent's scheme at chunk granularity: compare with one saved point,
+        // re-save when the chunk count is a power of two; a cycle of period p is found at most
+        // kChunk * p iterations after it has begun.
 #pragma unroll
-      for (int o = 0; o < kOrbitsPerLane; ++o) {
-        const bool in_full = lane_in(full_mask[o]);
-        if ((esc[o] | tail_mask[o]) != 0ull) {  // something ended in this chunk
-          const bool escaped = lane_in(esc[o]);
-          const bool push = escaped && (max_iter - l_rem[o] >= min_iter);
-          n_too_fast += (unsigned long long) __popcll(esc[o] & ~__ballot(push));
-          if (escaped || lane_in(tail_mask[o])) l_rem[o] = 0;
-          const unsigned long long push_mask = __ballot(push);
-          if (push_mask != 0ull) {
-            if (push) {
-              const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(push_mask));
-              q.q2_cr[slot] = lo[o].cr;
-              q.q2_ci[slot] = lo[o].ci;
-            }
-            q2_count += __popcll(push_mask);
-            if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-          }
+        for (int o = 0; o < kOrbitsPerLane; ++o) {
+          unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
+          const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
+          long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, uniform_u64(full_mask[o]),
+                      uniform_u64(esc[o]), accept_rem, long_steps_u, check_flag, q2_tail, q2_lds, push, ended,
+                      periodic);
+          n_too_fast += (unsigned long long) __popcll(esc[o] & ~push);
+          q2_count += __popcll(push);
+          if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+          n_never += (unsigned long long) (__popcll(ended) + __popcll(periodic));
         }
-        // orbits that went through the whole chunk without escaping
-        bool ended = false;
-        if (in_full && l_rem[o] >= kChunk) {
-          l_rem[o] -= kChunk;
-          ended = (l_rem[o] == 0);  // reached max_iter: IterateMandelbrot returns max (cudabrot.cu:339)
-          // Exact-periodicity early-out.  If z is bit for bit a value this orbit
-          // held at an earlier chunk boundary, the (deterministic) orbit repeats that stretch for
-          // ever and every point of the stretch passed the escape test: the sample can never
-          // escape, so IterateMandelbrot would return max_iterations -- the same outcome, without
-          // executing the remaining iterations.  Brent's scheme at chunk granularity: compare with
-          // one saved point, re-save when the chunk count is a power of two; a cycle of period p is
-          // found at most kChunk * p iterations after it has begun.
-          const bool periodic = (a.check_periodic != 0) && !ended &&
-                                (__double_as_longlong(lo[o].r) == __double_as_longlong(seen_r[o])) &&
-                                (__double_as_longlong(lo[o].i) == __double_as_longlong(seen_i[o]));
-          if (periodic) {
-            skipped_steps += (unsigned long long) l_rem[o];
-            l_rem[o] = 0;
-            ended = true;
-          } else {
-            const uint32_t chunks_done = (uint32_t) (long_steps - l_rem[o]) / (uint32_t) kChunk;
-            if ((chunks_done & (chunks_done - 1u)) == 0u) {
-              seen_r[o] = lo[o].r;
-              seen_i[o] = lo[o].i;
-            }
-          }
-        }
-        const unsigned long long ended_mask = __ballot(ended);
-        if (ended_mask != 0ull) n_never += (unsigned long long) __popcll(ended_mask);
       }
       // leave the stage when another one has work to do
       if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                       // REPLAY can fill every lane
@@ -1231,7 +1339,7 @@ draw_wave_kernel(DrawArgs a) {
     pl[17 * 64] = (unsigned long long) (uint32_t) p_steps | ((unsigned long long) (p_act ? 1u : 0u) << 32);
     pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32);
   }
-  const unsigned long long skipped_total = wave_sum(skipped_steps);
+  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
     const unsigned long long n_samples =

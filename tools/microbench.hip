@@ -71,102 +71,97 @@ void run_iterate(int waves_per_simd, int n) {
 }
 
 
-// The LONG stage's hand-written chunk (two orbits per lane, scalar live masks), copied from
-// cudabrot_amd/csrc/kernels.hip so that its bare rate can be read next to the product kernel's.
-#define MB_STEP2                                          \
+// The LONG stage's hand-written chunk (two orbits per lane, doubled coordinates: 6 fp64 instructions +
+// 1 compare per orbit-step), as in cudabrot_amd/csrc/draw_wave.hip (CB_STEP2), so that its bare rate can
+// be read next to the product kernel's.  Variants: 0 = scalar live masks + exact lane-step count (the
+// product's), 1 = live masks only (one s_and per orbit-step), 2 = vector instructions only.
+#define MB_V0(la, c0) "s_and_b64 " la ", " la ", " c0 "\n\t"
+#define MB_STEP2_GEN(S1, S2, S3, S4, S5, S6)              \
   "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
   "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
-  "s_and_b64 %[la], %[la], %[c0]\n\t"                     \
-  "v_add_f64 %[b0], %[ra], %[ra]\n\t"                     \
-  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
-  "v_add_f64 %[b1], %[rb], %[rb]\n\t"                     \
-  "s_bcnt1_i32_b64 %[t0], %[la]\n\t"                      \
+  S1                                                      \
   "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
-  "s_bcnt1_i32_b64 %[t1], %[lb]\n\t"                      \
+  S2                                                      \
   "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
-  "s_add_u32 %[cnt], %[cnt], %[t0]\n\t"                   \
-  "v_fma_f64 %[ia], %[b0], %[ia], %[cia]\n\t"             \
-  "s_add_u32 %[cnt], %[cnt], %[t1]\n\t"                   \
-  "v_fma_f64 %[ib], %[b1], %[ib], %[cib]\n\t"             \
-  "v_add_f64 %[ra], %[cra], %[a0]\n\t"                    \
-  "v_add_f64 %[rb], %[crb], %[a1]\n\t"                    \
+  S3                                                      \
+  "v_fma_f64 %[ia], %[ra], %[ia], %[cia]\n\t"             \
+  S4                                                      \
+  "v_fma_f64 %[ib], %[rb], %[ib], %[cib]\n\t"             \
+  S5                                                      \
+  "v_fma_f64 %[ra], %[a0], 0.5, %[cra]\n\t"               \
+  S6                                                      \
+  "v_fma_f64 %[rb], %[a1], 0.5, %[crb]\n\t"               \
   "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
   "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
   "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
   "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
-  "v_cmp_nlt_f64_e64 %[c0], 4.0, %[a0]\n\t"               \
-  "v_cmp_nlt_f64_e64 %[c1], 4.0, %[a1]\n\t"
-#define MB_STEP2X4 MB_STEP2 MB_STEP2 MB_STEP2 MB_STEP2
-#define MB_STEP2X16 MB_STEP2X4 MB_STEP2X4 MB_STEP2X4 MB_STEP2X4
-// variant without the scalar bookkeeping (pure VALU stream), for comparison
-#define MB_PURE2                                          \
-  "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
-  "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
-  "v_add_f64 %[b0], %[ra], %[ra]\n\t"                     \
-  "v_add_f64 %[b1], %[rb], %[rb]\n\t"                     \
-  "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
-  "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
-  "v_fma_f64 %[ia], %[b0], %[ia], %[cia]\n\t"             \
-  "v_fma_f64 %[ib], %[b1], %[ib], %[cib]\n\t"             \
-  "v_add_f64 %[ra], %[cra], %[a0]\n\t"                    \
-  "v_add_f64 %[rb], %[crb], %[a1]\n\t"                    \
-  "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
-  "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
-  "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
-  "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
-  "v_cmp_nlt_f64_e64 %[c0], 4.0, %[a0]\n\t"               \
-  "v_cmp_nlt_f64_e64 %[c1], 4.0, %[a1]\n\t"
-#define MB_PURE2X4 MB_PURE2 MB_PURE2 MB_PURE2 MB_PURE2
-#define MB_PURE2X16 MB_PURE2X4 MB_PURE2X4 MB_PURE2X4 MB_PURE2X4
+  "v_cmp_nlt_f64_e64 %[c0], %[k16], %[a0]\n\t"            \
+  "v_cmp_nlt_f64_e64 %[c1], %[k16], %[a1]\n\t"
+#define MB_STEP2 MB_STEP2_GEN("s_and_b64 %[la], %[la], %[c0]\n\t", "s_and_b64 %[lb], %[lb], %[c1]\n\t", \
+                              "s_bcnt1_i32_b64 %[t0], %[la]\n\t", "s_bcnt1_i32_b64 %[t1], %[lb]\n\t",   \
+                              "s_add_u32 %[cnt], %[cnt], %[t0]\n\t", "s_add_u32 %[cnt], %[cnt], %[t1]\n\t")
+#define MB_LATCH2 MB_STEP2_GEN("s_and_b64 %[la], %[la], %[c0]\n\t", "s_and_b64 %[lb], %[lb], %[c1]\n\t", "", "", "", "")
+#define MB_PURE2 MB_STEP2_GEN("", "", "", "", "", "")
+#define MB_X4(M) M M M M
+#define MB_X32(M) MB_X4(M) MB_X4(M) MB_X4(M) MB_X4(M) MB_X4(M) MB_X4(M) MB_X4(M) MB_X4(M)
 
-template <bool PURE>
+template <int VARIANT>
 __global__ void __launch_bounds__(256) chunk_kernel(int n_chunks, double *out, unsigned *cnt_out) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  double cra = -0.1 + 1e-4 * (tid % 977), cia = 0.05 + 1e-4 * (tid % 613);
-  double crb = -0.12 + 1e-4 * (tid % 811), cib = 0.04 + 1e-4 * (tid % 577);
+  double cra = -0.2 + 2e-4 * (tid % 977), cia = 0.1 + 2e-4 * (tid % 613);      // doubled coordinates
+  double crb = -0.24 + 2e-4 * (tid % 811), cib = 0.08 + 2e-4 * (tid % 577);
   double ra = cra, ia = cia, rb = crb, ib = cib;
   unsigned total = 0;
+  // the product rotates s_setprio among the four waves of a SIMD; here every wave keeps the level of its slot
+  const unsigned slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11)) & 3u;
+  if (slot == 0) __builtin_amdgcn_s_setprio(0);
+  if (slot == 1) __builtin_amdgcn_s_setprio(1);
+  if (slot == 2) __builtin_amdgcn_s_setprio(2);
+  if (slot == 3) __builtin_amdgcn_s_setprio(3);
   for (int c = 0; c < n_chunks; ++c) {
     unsigned long long la = ~0ull, lb = ~0ull, c0, c1;
     unsigned cnt, t0, t1;
-    double a0, a1, b0, b1;
-    if (PURE) {
-      asm volatile("s_mov_b32 %[cnt], 0\n\t" MB_PURE2X16 "s_and_b64 %[la], %[la], %[c0]\n\ts_and_b64 %[lb], %[lb], %[c1]\n\t"
-                   : [ra] "+v"(ra), [ia] "+v"(ia), [rb] "+v"(rb), [ib] "+v"(ib), [la] "+s"(la), [lb] "+s"(lb),
-                     [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [c0] "=&s"(c0), [c1] "=&s"(c1),
-                     [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)
-                   : [cra] "v"(cra), [cia] "v"(cia), [crb] "v"(crb), [cib] "v"(cib) : "scc");
+    double a0, a1;
+#define MB_OPERANDS                                                                                          \
+    : [ra] "+v"(ra), [ia] "+v"(ia), [rb] "+v"(rb), [ib] "+v"(ib), [la] "+s"(la), [lb] "+s"(lb), [a0] "=&v"(a0), \
+      [a1] "=&v"(a1), [c0] "=&s"(c0), [c1] "=&s"(c1), [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)          \
+    : [cra] "v"(cra), [cia] "v"(cia), [crb] "v"(crb), [cib] "v"(cib), [k16] "s"(16.0) : "scc"
+    if (VARIANT == 0) {
+      asm volatile("s_mov_b32 %[cnt], 0\n\ts_mov_b64 %[c0], -1\n\ts_mov_b64 %[c1], -1\n\t" MB_X32(MB_STEP2)
+                   "s_and_b64 %[la], %[la], %[c0]\n\ts_and_b64 %[lb], %[lb], %[c1]\n\t" MB_OPERANDS);
+    } else if (VARIANT == 1) {
+      asm volatile("s_mov_b32 %[cnt], 0\n\ts_mov_b64 %[c0], -1\n\ts_mov_b64 %[c1], -1\n\t" MB_X32(MB_LATCH2)
+                   "s_and_b64 %[la], %[la], %[c0]\n\ts_and_b64 %[lb], %[lb], %[c1]\n\t" MB_OPERANDS);
     } else {
-      asm volatile("s_mov_b32 %[cnt], 0\n\ts_mov_b64 %[c0], -1\n\ts_mov_b64 %[c1], -1\n\t" MB_STEP2X16
-                   "s_and_b64 %[la], %[la], %[c0]\n\ts_and_b64 %[lb], %[lb], %[c1]\n\t"
-                   : [ra] "+v"(ra), [ia] "+v"(ia), [rb] "+v"(rb), [ib] "+v"(ib), [la] "+s"(la), [lb] "+s"(lb),
-                     [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [c0] "=&s"(c0), [c1] "=&s"(c1),
-                     [cnt] "=&s"(cnt), [t0] "=&s"(t0), [t1] "=&s"(t1)
-                   : [cra] "v"(cra), [cia] "v"(cia), [crb] "v"(crb), [cib] "v"(cib) : "scc");
+      asm volatile("s_mov_b32 %[cnt], 0\n\t" MB_X32(MB_PURE2)
+                   "s_and_b64 %[la], %[la], %[c0]\n\ts_and_b64 %[lb], %[lb], %[c1]\n\t" MB_OPERANDS);
     }
+#undef MB_OPERANDS
     total += cnt + (unsigned) __popcll(la & lb);
   }
   out[tid] = ra + ia + rb + ib;
   if ((threadIdx.x & 63) == 0) cnt_out[tid >> 6] = total;
 }
 
-template <bool PURE>
+template <int VARIANT>
 void run_chunk(int waves_per_simd, int n_chunks) {
   const int blocks = 256 * waves_per_simd;
   double *out; unsigned *cnt;
   CK(hipMalloc(&out, sizeof(double) * blocks * 256));
   CK(hipMalloc(&cnt, sizeof(unsigned) * blocks * 4));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  hipLaunchKernelGGL(chunk_kernel<PURE>, dim3(blocks), dim3(256), 0, 0, n_chunks / 8, out, cnt);
+  hipLaunchKernelGGL(chunk_kernel<VARIANT>, dim3(blocks), dim3(256), 0, 0, n_chunks / 8, out, cnt);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  hipLaunchKernelGGL(chunk_kernel<PURE>, dim3(blocks), dim3(256), 0, 0, n_chunks, out, cnt);
+  hipLaunchKernelGGL(chunk_kernel<VARIANT>, dim3(blocks), dim3(256), 0, 0, n_chunks, out, cnt);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
-  const double iters = (double) blocks * 256 * 2 * 16 * n_chunks;
+  const double iters = (double) blocks * 256 * 2 * 32 * n_chunks;
   const double rate = iters / (ms * 1e-3);
-  printf("asm chunk (2 orbits/lane, %s) waves/simd=%d : %.3f ms  %.3f Titer/s  issue(8 ops/iter)=%.1f%% of 39.3T\n",
-         PURE ? "VALU only" : "with scalar masks+count", waves_per_simd, ms, rate / 1e12, 100.0 * rate * 8 / 39.32e12);
+  static const char *const kName[] = {"live masks + exact count", "live masks only", "vector only"};
+  printf("asm chunk (2 orbits/lane, 6+1 per step, %s) waves/simd=%d : %.3f ms  %.3f Titer/s  %.1f TFLOP/s(10/iter)  "
+         "issue(7 slots/iter)=%.1f%% of 39.3T\n",
+         kName[VARIANT], waves_per_simd, ms, rate / 1e12, rate * 10 / 1e12, 100.0 * rate * 7 / 39.32e12);
   CK(hipFree(out)); CK(hipFree(cnt));
 }
 
@@ -214,8 +209,9 @@ int main() {
   for (int w = 1; w <= 8; w *= 2) run_iterate<1>(w, 40000);
   for (int w = 1; w <= 4; w *= 2) run_iterate<2>(w, 40000);
   for (int w = 1; w <= 2; w *= 2) run_iterate<4>(w, 40000);
-  for (int w = 1; w <= 4; w *= 2) run_chunk<false>(w, 3000);
-  for (int w = 1; w <= 4; w *= 2) run_chunk<true>(w, 3000);
+  for (int w = 1; w <= 4; w *= 2) run_chunk<0>(w, 1500);
+  for (int w = 1; w <= 4; w *= 2) run_chunk<1>(w, 1500);
+  for (int w = 1; w <= 4; w *= 2) run_chunk<2>(w, 1500);
   if (getenv("MB_SKIP_SCATTER")) return 0;
   const unsigned long long small = 4096ull * 4096ull, big = 20000ull * 20000ull;
   unsigned long long *buf; CK(hipMalloc(&buf, big * 8)); CK(hipMemset(buf, 0, big * 8));
