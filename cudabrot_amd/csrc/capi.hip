@@ -298,7 +298,8 @@ int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_thre
 }
 
 size_t cb_carry_bytes(uint32_t n_threads) {
-  return (size_t) cb::draw_wave_count(n_threads) * cb::kCarryWordsPerWave * sizeof(unsigned long long);
+  return (size_t) cb::draw_wave_count(n_threads) * cb::kCarryWordsPerWave * sizeof(unsigned long long) +
+         (size_t) cb::kSchedWords * sizeof(uint32_t);
 }
 
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
@@ -334,6 +335,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
       a.check_periodic = 0;
       return (int) wave(a, false, s);
     case CB_KERNEL_TIMED:
+      if (getenv("CUDABROT_AMD_TIMED_FULL")) a.check_periodic = 0;  // diagnostic: stage clocks of the full-iterate form
       return (int) wave(a, true, s);
     case CB_KERNEL_SIMPLE:
       return (int) cb::launch_draw_simple(a, s);

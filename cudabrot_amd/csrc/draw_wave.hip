@@ -925,6 +925,40 @@ draw_wave_kernel(DrawArgs a) {
   static_assert(sizeof(WaveQueues) == kCarryQueueWords * 8, "carry layout follows WaveQueues");
   unsigned long long *const carry =
       a.carry ? a.carry + (size_t) wave_id * kCarryWordsPerWave : nullptr;
+  // Progress board (kernels.h, kSchedWords; only with a carry buffer).  VALU issue goes by priority,
+  // then by wave age, and a wave alone on its SIMD cannot fill the fp64 pipe: left to themselves the four
+  // waves of a SIMD end 25 % of the launch apart (measured), and the launch lasts as long as the slowest.
+  // So the waves that share a SIMD post how many samples they still have to draw in a row of the board
+  // and take s_setprio from their rank: the one furthest behind issues first.  A heuristic on top of a
+  // result that no schedule can change; stale or torn values only cost time.
+  uint32_t *board_row = nullptr;
+  if (a.carry) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+    const uint32_t key = ((xcc & 0xfu) << 12) | ((hw >> 4) & 0xfffu);                  // SIMD, pipe, CU, SH, SE
+    board_row = reinterpret_cast<uint32_t *>(a.carry + (size_t) gridDim.x * kWavesPerBlock * kCarryWordsPerWave) +
+                (size_t) key * 16u;
+  }
+  auto post_progress_and_set_priority = [&](uint32_t still_to_draw) {
+    const uint32_t mine = still_to_draw + 1u;  // 0 = no wave in this slot
+    const uint32_t lane = (uint32_t) lane_id();
+    if (lane == 0u) {
+      __hip_atomic_store(board_row + (wave_slot & 15u), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t other = 0u;
+    if (lane < 16u) other = __hip_atomic_load(board_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // waves of this SIMD that are further behind (ties: the lower slot first)
+    const bool before_me = (lane < 16u) && (lane != (wave_slot & 15u)) &&
+                           (other > mine || (other == mine && lane < (wave_slot & 15u)));
+    const int rank = __popcll(__ballot(before_me));
+    switch (rank) {
+      case 0: __builtin_amdgcn_s_setprio(3); break;
+      case 1: __builtin_amdgcn_s_setprio(2); break;
+      case 2: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(0); break;
+    }
+  };
+  if (board_row) post_progress_and_set_priority(a.samples_per_thread);
   if (carry && carry[0] == 1ull) {  // wave-uniform: the header is one address
     q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
     q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));
@@ -1082,6 +1116,7 @@ draw_wave_kernel(DrawArgs a) {
     if (!feed_input_done && q0_count < 64) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       samples_left--;
+      if (board_row && (samples_left & 31u) == 0u) post_progress_and_set_priority(samples_left);
       if constexpr (fast_head) {  // the usual split (plan_stages): one asm block each for the draw and the test
         double c_re, c_im;
         head_draw(rot, c_re, c_im);  // cudabrot.cu:392-393
@@ -1217,7 +1252,9 @@ draw_wave_kernel(DrawArgs a) {
       // where one wave cannot fill the fp64 pipe (measured: the 4 waves of a SIMD ended at 31 / 40 /
       // 53 / 65 ms of a 65 ms kernel).  Each wave therefore walks through the four priority levels
       // as it progresses, offset by its wave slot.
-      if ((long_chunks & (kPrioChunks - 1u)) == 0u) {
+      if (board_row) {
+        if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(samples_left);
+      } else if ((long_chunks & (kPrioChunks - 1u)) == 0u) {
         switch ((wave_slot + long_chunks / kPrioChunks) & 3u) {
           case 0: __builtin_amdgcn_s_setprio(0); break;
           case 1: __builtin_amdgcn_s_setprio(1); break;
@@ -1301,6 +1338,9 @@ draw_wave_kernel(DrawArgs a) {
     if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
   }
 
+  if (board_row && lane_id() == 0) {  // this wave no longer competes
+    __hip_atomic_store(board_row + (wave_slot & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if constexpr (kFastHead) rng = head_registers_read();
   switch (rot) {  // back to the logical order of the generator words
     case 1: rng = xorwow_unrotated<1>(rng); break;

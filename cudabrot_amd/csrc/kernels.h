@@ -122,6 +122,11 @@ constexpr uint32_t kCarryHeaderWords = 8;
 constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 96 + 2 * 192);  // = sizeof(WaveQueues) / 8
 constexpr uint32_t kCarryLanePlanes = 19;
 constexpr uint32_t kCarryWordsPerWave = kCarryHeaderWords + kCarryQueueWords + kCarryLanePlanes * 64;
+// Behind the per-wave records of a carry buffer: the progress board of the draw kernel's waves, 16 words
+// per SIMD (one per wave slot), indexed by (XCC, SE, SH, CU, SIMD).  The waves that share a SIMD post how
+// many samples they still have to draw and take their issue priority from their rank (draw_wave.hip).
+constexpr uint32_t kSchedKeys = 1u << 16;
+constexpr uint32_t kSchedWords = kSchedKeys * 16u;  // u32 words
 
 constexpr uint32_t kDrawBlockThreads = 256;  // 4 waves per workgroup
 inline uint32_t draw_wave_count(uint32_t n_threads) {
