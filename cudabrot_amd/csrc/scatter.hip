@@ -296,15 +296,14 @@ template <bool kLevelA>
 __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout b) {
   using P = Pass<kLevelA>;
   extern __shared__ uint32_t lds[];
-  // dynamic LDS: cursor[nk] | cnt[nk] | lstart[nk] | wave_totals[8] | pos[chunk] | payload[chunk]
+  // dynamic LDS: bounds[nk] {start of the key's run in the sorted chunk, its next place in the output} |
+  // cnt[nk] | wave_totals[8] | sorted[chunk] {place in the output, payload}.  Pairs, so that sorting an
+  // entry is one 8-byte read and one 8-byte write and copying it out one 8-byte read.
   const uint32_t nk_lds = P::n_keys(b);
-  uint32_t *cursor = lds;
-  uint32_t *cnt = cursor + nk_lds;
-  uint32_t *lstart = cnt + nk_lds;
-  uint32_t *wave_totals = lstart + nk_lds;
-  uint32_t *pos = wave_totals + 8;
-  uint32_t *pay32 = pos + kChunkEntries;                                 // level A: whole entries
-  uint16_t *pay16 = reinterpret_cast<uint16_t *>(pos + kChunkEntries);  // level B: in-tile offsets
+  uint2 *bounds = reinterpret_cast<uint2 *>(lds);
+  uint32_t *cnt = lds + 2u * nk_lds;
+  uint32_t *wave_totals = cnt + nk_lds;
+  uint2 *sorted = reinterpret_cast<uint2 *>(wave_totals + 8);
 
   const uint32_t r = blockIdx.x;
   if (r >= P::n_regions(b)) return;
@@ -317,7 +316,7 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
   const unsigned long long *bases = P::bases(b);
   for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) {
     // all entries together are < 2^32, so 32-bit places suffice
-    cursor[t] = (uint32_t) bases[k0 + t] + counts[(size_t) (k0 + t) * stride + col];
+    bounds[t].y = (uint32_t) bases[k0 + t] + counts[(size_t) (k0 + t) * stride + col];
   }
   const uint32_t bins_per_thread = (nk + kScatterThreads - 1u) / kScatterThreads;
 
@@ -345,7 +344,7 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
       }
     }
     __syncthreads();
-    // 2. exclusive scan of cnt over keys -> lstart (start of each key's run in the sorted chunk)
+    // 2. exclusive scan of cnt over keys -> start of each key's run in the sorted chunk
     {
       const uint32_t t0 = threadIdx.x * bins_per_thread;
       uint32_t sum = 0;
@@ -356,7 +355,7 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
       uint32_t run = block_exclusive_scan(sum, wave_totals, &total);
       for (uint32_t k = 0; k < bins_per_thread; ++k) {
         if (t0 + k < nk) {
-          lstart[t0 + k] = run;
+          bounds[t0 + k].x = run;
           run += cnt[t0 + k];
         }
       }
@@ -367,23 +366,24 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       if (key[k] != ~0u) {
-        const uint32_t lp = lstart[key[k]] + rank[k];
-        pos[lp] = cursor[key[k]] + rank[k];
-        if (kLevelA) {
-          pay32[lp] = e[k];
-        } else {
-          pay16[lp] = (uint16_t) offset_of(e[k], b);
-        }
+        const uint2 bd = bounds[key[k]];
+        sorted[bd.x + rank[k]] = make_uint2(bd.y + rank[k], kLevelA ? e[k] : offset_of(e[k], b));
       }
     }
     __syncthreads();
-    // 4. write the runs out (consecutive lanes -> consecutive places of a run) and advance cursors
+    // 4. write the runs out (consecutive lanes -> consecutive places of a run) and advance the places
     if (kLevelA) {
-      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) b.grouped[pos[i]] = pay32[i];
+      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) {
+        const uint2 v = sorted[i];
+        b.grouped[v.x] = v.y;
+      }
     } else {
-      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) b.sorted[pos[i]] = pay16[i];
+      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) {
+        const uint2 v = sorted[i];
+        b.sorted[v.x] = (uint16_t) v.y;
+      }
     }
-    for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) cursor[t] += cnt[t];
+    for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) bounds[t].y += cnt[t];
     __syncthreads();
   }
 }
@@ -606,9 +606,8 @@ hipError_t launch_pass(const BinLayout &b, uint32_t n_keys_lds, uint32_t total_k
   hipLaunchKernelGGL((bin_scan_rows_kernel<kLevelA>), dim3(total_keys), dim3(256), 0, stream, b);
   hipLaunchKernelGGL((bin_scan_keys_kernel<kLevelA>), dim3(1), dim3(1024), 0, stream, b);
   if (kLevelA) hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(64), 0, stream, b);
-  const size_t scatter_lds = ((size_t) 3 * n_keys_lds + 8 + kChunkEntries) * sizeof(uint32_t) +
-                             (size_t) kChunkEntries * (kLevelA ? sizeof(uint32_t) : sizeof(uint16_t));
-  if (scatter_lds > 64 * 1024) {  // up to 96 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
+  const size_t scatter_lds = ((size_t) 3 * n_keys_lds + 8 + 2 * kChunkEntries) * sizeof(uint32_t);
+  if (scatter_lds > 64 * 1024) {  // 76 KiB at 1024 keys, 112 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_scatter_kernel<kLevelA>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) scatter_lds);
     if (e != hipSuccess) return e;
