@@ -71,6 +71,7 @@ constexpr int kQ1Low = 32;             // run MID while fewer deep orbits than t
 constexpr int kQ1Exit = 8;             // LONG hands over to HEAD / MID below this many
 constexpr int kReplayMin = 40;         // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = 16;  // replay steps per asm burst
+constexpr uint32_t kBrentBits = 2;     // periodicity check: re-save when the chunk count has no bits below its top 2
 constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
 
 struct WaveQueues {
@@ -599,9 +600,12 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
 #define CB_RETIRE_TAIL                                     \
       "v_sub_u32 %[t], %[ls], %[lrem]\n\t"               \
       "v_lshrrev_b32 %[t], 5, %[t]\n\t"                  \
-      "v_add_u32 %[slot], -1, %[t]\n\t"                  \
-      "v_and_b32 %[slot], %[slot], %[t]\n\t"             \
-      "v_cmpx_eq_u32_e32 vcc, 0, %[slot]\n\t"            \
+      "v_ffbh_u32 %[slot], %[t]\n\t"                     \
+      "v_sub_u32 %[slot], %[kbits], %[slot]\n\t"         \
+      "v_max_i32 %[slot], 0, %[slot]\n\t"                \
+      "v_lshrrev_b32 %[t2], %[slot], %[t]\n\t"           \
+      "v_lshlrev_b32 %[t2], %[slot], %[t2]\n\t"          \
+      "v_cmpx_eq_u32_e32 vcc, %[t], %[t2]\n\t"           \
       "v_mov_b64 %[sr], %[r]\n\t"                        \
       "v_mov_b64 %[si], %[i]\n\t"                        \
       "3:\n\t"                                           \
@@ -638,8 +642,12 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
 //   the others       l_rem -= 32; `ended`: reached max_iter (IterateMandelbrot returns max,
 //                    cudabrot.cu:339); `periodic` (check_periodic != 0 only): z is bit for bit the saved
 //                    point, so the orbit repeats for ever and can never escape -- retired with the
-//                    remaining iterations added to skip (two 32-bit halves); else Brent's schedule:
-//                    re-save z when the number of chunks done is a power of two
+//                    remaining iterations added to skip (two 32-bit halves); else Brent's schedule,
+//                    refined: re-save z when the number of chunks done has no set bit below its top
+//                    kBrentBits = 2 (1, 1.5, 2, 3, 4, 6 ... chunks).  The saved point must be older than
+//                    the cycle is long, yet young enough to lie on the cycle: measured at C3, this
+//                    schedule executes 3 % fewer iterations than powers of two alone, and keeping the
+//                    top three bits 8 % more
 __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, double &seen_i, int &l_rem,
                                             uint32_t &skip_lo, uint32_t &skip_hi, unsigned long long ran,
                                             unsigned long long esc, int accept_rem, uint32_t long_steps,
@@ -648,13 +656,14 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
                                             unsigned long long &periodic) {
   static_assert(kQ2Cap == 192 && kChunk == 32, "ring length, plane distance and chunk length below");
   unsigned long long save;
-  uint32_t slot, t;
+  uint32_t slot, t, t2;
 #define CB_RETIRE_OPERANDS                                                                                   \
   : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),      \
     [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic), [save] "=&s"(save), [slot] "=&v"(slot), \
+    [t2] "=&v"(t2),                                                                                          \
     [t] "=&v"(t)                                                                                             \
   : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),       \
-    [chkf] "s"(check_periodic),                                                                              \
+    [chkf] "s"(check_periodic), [kbits] "s"(32u - kBrentBits),                                               \
     [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)                             \
   : "vcc", "scc", "memory"
   asm volatile(CB_RETIRE_ESCAPED CB_RETIRE_SURVIVORS CB_RETIRE_TAIL CB_RETIRE_OPERANDS);
