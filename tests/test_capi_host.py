@@ -112,3 +112,29 @@ def test_save_image_bytes(cb, oracle, tmp_path):
     body = np.frombuffer(data[len(b"P5\n37 11\n65535\n"):], dtype=">u2").reshape(11, 37)
     assert np.array_equal(body, gray)
     assert cb.save_image(str(tmp_path / "no_such_dir" / "x.pgm"), gray) == 1  # open failure is reported
+
+
+def test_header_is_plain_c_and_the_library_links_from_c(cb, repo_root, tmp_path):
+    """include/cudabrot_amd.h is the drop-in boundary for a C host program (the reference is C): it must compile
+    as C99 with warnings on, and a C program must link against the shared library."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text(
+        '#include "cudabrot_amd.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "  cb_fractal_dimensions d = {0};\n  const char *msg = 0;\n"
+        "  d.w = 10; d.h = 10; d.min_real = -2; d.max_real = 2; d.min_imag = -2; d.max_imag = 2;\n"
+        '  printf("%d %d %d %d\\n", cb_recompute_pixel_deltas(&d, &msg), (int) sizeof(cb_counters),\n'
+        "         (int) cb_rng_state_bytes(64), (int) cb_tone_value(5, 10, 1.0));\n  return 0;\n}\n")
+    libdir = os.path.dirname(cb.library_path())
+    exe = str(tmp_path / "t")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(repo_root, "include"),
+                        str(src), "-L", libdir, "-lcudabrot_amd", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.split() == ["1", "136", "1536", "32767"]
