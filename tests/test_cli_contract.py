@@ -49,6 +49,13 @@ def test_help_prints_usage_and_exits_zero(exe):
         (["--max-imag", "-2"], "Minimum imaginary value must be greater than maximum imaginary value."),
         # flag ORDER matters: the canvas is re-validated after each flag (cudabrot.cu:704-749)
         (["--min-real", "3", "--max-real", "4"], "Maximum real value must be greater than minimum real value."),
+        # extension flags follow the same conventions
+        (["--gpus"], "Argument --gpus needs a value."),
+        (["--passes", "many"], "Invalid number given to argument --passes: many"),
+        (["--channel", "100:20"], "Invalid channel (want MAX:MIN:FILE, at most 4 of them): 100:20"),
+        (["--channel", "a:b:c"], "Invalid channel (want MAX:MIN:FILE, at most 4 of them): a:b:c"),
+        (["--channel", "9:1:a", "--channel", "9:1:b", "--channel", "9:1:c", "--channel", "9:1:d", "--channel", "9:1:e"],
+         "Invalid channel (want MAX:MIN:FILE, at most 4 of them): 9:1:e"),
     ],
 )
 def test_bad_arguments_print_message_then_usage_and_exit_zero(exe, args, first_line):
