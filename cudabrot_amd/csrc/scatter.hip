@@ -55,7 +55,9 @@ __device__ __forceinline__ uint32_t tile_of(uint32_t e, const BinLayout &b) {
   return (((e >> b.e_row_shift) & b.e_row_mask) >> kTileShift) * b.tiles_x + ((e & b.e_col_mask) >> kTileShift);
 }
 __device__ __forceinline__ uint32_t offset_of(uint32_t e, const BinLayout &b) {
-  return (((e >> b.e_row_shift) & (kTileSize - 1u)) << kTileShift) | (e & (kTileSize - 1u));
+  // a canvas narrower (lower) than a tile has a column (row) field of fewer bits than a tile coordinate
+  return (((e >> b.e_row_shift) & b.e_row_mask & (kTileSize - 1u)) << kTileShift) |
+         (e & b.e_col_mask & (kTileSize - 1u));
 }
 __device__ __forceinline__ bool taken(uint32_t e, const BinLayout &b) {
   return b.channel < 0 || (((e >> b.e_chan_shift) >> b.channel) & 1u) != 0u;

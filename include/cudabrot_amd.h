@@ -160,7 +160,13 @@ int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32
  * channel j whose window windows[j].min <= k < windows[j].max holds the escape index k.  d_hist is
  * n_channels planes of w*h counters, plane j = what cb_draw_buddhabrot would add with windows[j].
  * The wave-scheduled kernel only (variant flags as above); cb_flush_scatter_channels after each
- * launch that was given a workspace (sized by cb_scatter_workspace_bytes). */
+ * launch that was given a workspace (sized by cb_scatter_workspace_bytes).
+ * Counters of a fused launch: samples, rejected, never_escaped (against the largest max) and
+ * iterate_steps as for one run with the largest max; too_fast = orbits that escaped but whose index
+ * lies in no window; recorded = orbits in at least one window; replay_steps counts both replays (the
+ * first, unrecorded one finds the escape index); increments = in-canvas points recorded, each of which
+ * adds one to EVERY plane of its orbit's channel set (so the planes' sum is >= increments, with
+ * equality when the windows are disjoint). */
 int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                                 const cb_iteration_control *windows, int n_channels, void *d_states,
                                 uint32_t n_threads, uint32_t samples_per_thread, cb_counters *d_counters,

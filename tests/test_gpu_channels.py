@@ -77,6 +77,19 @@ def test_fused_channels_on_a_canvas_that_divides_and_needs_two_sort_levels(cb, o
         assert np.array_equal(planes[j], ref)
 
 
+@pytest.mark.parametrize("w,h", [(7, 127), (64, 40), (300, 5), (1, 1)])
+def test_fused_channels_on_a_canvas_smaller_than_a_tile(cb, oracle, w, h):
+    """The stream word's row / column fields are as narrow as the canvas allows: narrower than a tile
+    coordinate here (found by tools/gpu_fuzz.py: the in-tile offset took bits of the neighbouring field)."""
+    windows = [(30, 5), (100, 50)]
+    t, passes = 4096, 2
+    planes, cnt = _fused(cb, w, h, windows, t, passes, "binned")
+    assert cnt["status"] == 0
+    for j, (m, c) in enumerate(windows):
+        ref, _ = oracle.render(w, h, m, c, t, passes)
+        assert np.array_equal(planes[j], ref), "channel %d" % j
+
+
 def test_too_many_channels_or_the_simple_kernel_are_rejected(cb):
     dims = cb.FractalDimensions.make(64, 64)
     with pytest.raises(cb.CudabrotError):

@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""gpu_fuzz.py -- randomized A/B of the product kernel against the lock-step validation kernel.
+
+Both run on the GPU through the C ABI; `draw_simple_kernel` is one lane per reference thread with the
+reference's arithmetic and direct atomics and is itself pinned against the oracle by the
+test-suite.  Each trial draws a random shape -- canvas size and box (dyadic and non-dyadic pixel deltas,
+off-centre and partly empty windows), iteration window, thread count (ragged), samples per launch, number
+of launches, with / without scatter workspace (suggested or deliberately short), with / without carry buffer
+(then ended by a drain launch or the drain flag), Mandelbrot / Burning Ship, seed and first subsequence --
+and demands identical histograms and counters.
+
+    python tools/gpu_fuzz.py [SECONDS] [SEED]      exit 1 at the first mismatch (the trial is printed)
+"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+import cudabrot_amd as cb
+
+COMPARED = ("samples", "rejected", "never_escaped", "too_fast", "recorded", "iterate_steps", "replay_steps",
+            "increments", "status")
+
+
+def trial(rng):
+    t = {}
+    big = rng.random() < 0.15
+    t["w"] = rng.choice([1, 2, 7, 64, 100, 128, 129, 255, 256, 333, 512, 640, 1000]) if not big else rng.choice([2048, 3000, 4096])
+    t["h"] = rng.choice([1, 3, 8, 64, 100, 127, 128, 200, 256, 384, 512, 777, 1000]) if not big else rng.choice([1024, 2500, 4096])
+    kind = rng.random()
+    if kind < 0.4:
+        t["box"] = (-2.0, 2.0, -2.0, 2.0)
+    elif kind < 0.6:
+        t["box"] = (-2.0, 1.0, -1.5, 1.5)
+    elif kind < 0.8:   # random window, usually a non-dyadic delta
+        cx, cy = rng.uniform(-1.5, 0.5), rng.uniform(-1.0, 1.0)
+        rx, ry = rng.uniform(0.05, 2.0), rng.uniform(0.05, 2.0)
+        t["box"] = (cx - rx, cx + rx, cy - ry, cy + ry)
+    else:              # far from the set: almost nothing lands
+        t["box"] = (1.0, 3.0, 1.0, 2.5)
+    t["max_iter"] = rng.choice([1, 2, 5, 19, 20, 21, 33, 64, 100, 257, 1000, 2000, 5000, 20000])
+    t["min_iter"] = rng.choice([0, 1, 2, 19, 20, 21, 32, 40, 99, 1000, 30000])
+    t["threads"] = rng.choice([1, 63, 64, 65, 200, 256, 1000, 1024, 4096, 5000, 16384])
+    t["launch_samples"] = [rng.choice([1, 2, 7, 50, 64, 100, 150]) for _ in range(rng.randint(1, 4))]
+    t["workspace"] = rng.choice(["suggested", "suggested", "short", "none"])
+    t["carry"] = rng.choice(["none", "drain_launch", "drain_flag"])
+    t["ship"] = rng.random() < 0.2
+    t["seed"] = rng.choice([1337, 1337, 1, 0xdeadbeefcafe])
+    t["first"] = rng.choice([0, 0, 1, 262144, 2097151])
+    t["two_level"] = rng.random() < 0.2          # the large-canvas sort on any canvas (test knob)
+    t["windows"] = None
+    if rng.random() < 0.25:                      # fused multi-channel launch: plane j == a run with window j
+        t["windows"] = [(rng.choice([30, 100, 400, 2500]), rng.choice([0, 5, 20, 50, 300])) for _ in range(rng.randint(1, 4))]
+    if t["max_iter"] >= 5000:   # keep the lock-step kernel's run time in hand
+        t["threads"] = min(t["threads"], 4096)
+    return t
+
+
+def render(t, variant, window=None, fused=False):
+    """window: (max, min) instead of the trial's; fused: all of t["windows"] in one launch (planes)."""
+    dev = torch.device("cuda", 0)
+    dims = cb.FractalDimensions.make(t["w"], t["h"], *t["box"])
+    it = cb.IterationControl(*(window or (t["max_iter"], t["min_iter"])))
+    planes = len(t["windows"]) if fused else 1
+    n = t["threads"]
+    flags = cb.CB_KERNEL_FLAG_BURNING_SHIP if t["ship"] else 0
+    states = torch.empty(cb.rng_state_bytes(n), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(planes * t["w"] * t["h"], dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(t["seed"], t["first"], n, states.data_ptr(), stream)
+    simple = variant == cb.CB_KERNEL_SIMPLE
+    if t["two_level"] and not simple:
+        os.environ["CUDABROT_AMD_TWO_LEVEL"] = "1"
+    else:
+        os.environ.pop("CUDABROT_AMD_TWO_LEVEL", None)
+    ws_bytes = 0
+    if not simple and t["workspace"] != "none":
+        ws_bytes = cb.scatter_workspace_bytes(dims, n, max(t["launch_samples"]))
+        if t["workspace"] == "short":
+            ws_bytes = ws_bytes // 3
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    use_carry = (not simple) and t["carry"] != "none"
+    carry = torch.zeros(cb.carry_bytes(n) if use_carry else 1, dtype=torch.uint8, device=dev)
+
+    def launch(samples, extra=0):
+        if fused:
+            cb.draw_buddhabrot_channels(dims, hist.data_ptr(), t["windows"], states.data_ptr(), n, samples,
+                                        counters.data_ptr(), variant | flags | extra, stream,
+                                        ws.data_ptr() if ws_bytes else 0, ws_bytes,
+                                        carry.data_ptr() if use_carry else 0)
+            if ws_bytes:
+                cb.flush_scatter_channels(dims, hist.data_ptr(), planes, n, ws.data_ptr(), ws_bytes, stream)
+            return
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), n, samples, counters.data_ptr(),
+                           variant | flags | extra, stream, ws.data_ptr() if ws_bytes else 0, ws_bytes,
+                           carry.data_ptr() if use_carry else 0)
+        if ws_bytes:
+            cb.flush_scatter(dims, hist.data_ptr(), n, ws.data_ptr(), ws_bytes, stream)
+
+    for i, s in enumerate(t["launch_samples"]):
+        last = i == len(t["launch_samples"]) - 1
+        launch(s, cb.CB_KERNEL_FLAG_DRAIN if (use_carry and last and t["carry"] == "drain_flag") else 0)
+    if use_carry and t["carry"] == "drain_launch":
+        launch(0)
+    torch.cuda.synchronize()
+    c = counters.cpu().numpy().view(np.uint64)
+    cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in c)))
+    return hist.cpu().numpy().view(np.uint64), cnt
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = random.Random(seed)
+    t_end = time.time() + seconds
+    n = 0
+    last_print = time.time()
+    while time.time() < t_end:
+        t = trial(rng)
+        try:
+            if t["windows"]:
+                got, gc = render(t, cb.CB_KERNEL_DEFAULT, fused=True)
+                singles = [render(t, cb.CB_KERNEL_SIMPLE, window=w) for w in t["windows"]]
+                want = np.concatenate([h for h, _ in singles])
+                wc = dict(gc)                      # per-window counters do not add up to the fused run's ...
+                wc["samples"] = singles[0][1]["samples"]
+                wc["rejected"] = singles[0][1]["rejected"]
+                # ... and `increments` counts recorded points, not the planes they went to (cudabrot_amd.h)
+                each = [c["increments"] for _, c in singles]
+                if not (max(each) <= gc["increments"] <= sum(each)) or int(got.sum()) != sum(each):
+                    wc["increments"] = -1
+            else:
+                want, wc = render(t, cb.CB_KERNEL_SIMPLE)
+                got, gc = render(t, cb.CB_KERNEL_DEFAULT)
+        except cb.CudabrotError as e:
+            print("trial %d: error %s\n  %r" % (n, e, t), flush=True)
+            return 1
+        bad = [k for k in COMPARED if wc[k] != gc[k]]
+        if not np.array_equal(want, got) or bad:
+            print("MISMATCH at trial %d (seed %d): %r" % (n, seed, t))
+            print("  counters that differ: %r" % [(k, wc[k], gc[k]) for k in bad])
+            print("  pixels that differ: %d of %d; sums %d vs %d" % (int((want != got).sum()), want.size,
+                                                                     int(want.sum()), int(got.sum())), flush=True)
+            return 1
+        n += 1
+        if time.time() - last_print > 30:
+            print("%d trials identical so far" % n, flush=True)
+            last_print = time.time()
+    print("gpu_fuzz: %d trials, histograms and counters identical (seed %d)" % (n, seed))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
