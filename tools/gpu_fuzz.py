@@ -5,7 +5,8 @@ Both run on the GPU through the C ABI; `draw_simple_kernel` is one lane per refe
 reference's arithmetic and direct atomics and is itself pinned against the oracle by the
 test-suite.  Each trial draws a random shape -- canvas size and box (dyadic and non-dyadic pixel deltas,
 off-centre and partly empty windows), iteration window, thread count (ragged), samples per launch, number
-of launches, with / without scatter workspace (suggested or deliberately short), with / without carry buffer
+of launches (or the cb_renderer object with its pipelined launches, early reads and a resume into a new
+renderer), with / without scatter workspace (suggested or deliberately short), with / without carry buffer
 (then ended by a drain launch or the drain flag), Mandelbrot / Burning Ship, seed and first subsequence --
 and demands identical histograms and counters.
 
@@ -115,6 +116,53 @@ def render(t, variant, window=None, fused=False):
     return hist.cpu().numpy().view(np.uint64), cnt
 
 
+def renderer_trial(rng):
+    """The owned-object form (cb_renderer: two workspaces and streams, carry, lazy drain, resume)."""
+    t = trial(rng)
+    t["threads"] = rng.choice([64, 200, 1024, 4096])
+    t["max_iter"] = min(t["max_iter"], 2000)
+    t["calls"] = [rng.choice([1, 2, 3, 7, 64, 70]) for _ in range(rng.randint(1, 3))]
+    if sum(t["calls"]) > 80:
+        t["calls"] = [3, 66]
+    t["per_launch"] = rng.choice([None, 1, 2, 5, 64])
+    t["no_workspace"] = rng.random() < 0.2
+    t["read_between"] = rng.random() < 0.3       # reading the histogram drains the carried orbits early
+    t["resume_at"] = rng.choice([None, None, 0, 1])   # after this call: states + histogram into a NEW renderer
+    t["launch_samples"] = [50 * sum(t["calls"])]
+    return t
+
+
+def render_with_renderer(t):
+    for k, v in (("CUDABROT_AMD_PASSES_PER_LAUNCH", t["per_launch"]), ("CUDABROT_AMD_NO_WORKSPACE", 1 if t["no_workspace"] else None),
+                 ("CUDABROT_AMD_TWO_LEVEL", 1 if t["two_level"] else None)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    dims = cb.FractalDimensions.make(t["w"], t["h"], *t["box"])
+    what = t["windows"] if t["windows"] else cb.IterationControl(t["max_iter"], t["min_iter"])
+    flags = cb.CB_KERNEL_FLAG_BURNING_SHIP if t["ship"] else 0
+    r = cb.Renderer(dims, what, seed=t["seed"], first_subsequence=t["first"], n_threads=t["threads"])
+    try:
+        for i, passes in enumerate(t["calls"]):
+            r.render_passes(passes, cb.CB_KERNEL_DEFAULT | flags)
+            if t["read_between"]:
+                r.read_histogram()
+            if t["resume_at"] == i:
+                hist, states = r.read_histogram(), r.read_rng_states()
+                r.close()
+                r = cb.Renderer(dims, what, seed=99, first_subsequence=5, n_threads=t["threads"])
+                r.write_histogram(hist)
+                r.write_rng_states(states)
+        hist = r.read_histogram().reshape(-1)
+        status = r.read_counters().status
+    finally:
+        r.close()
+        for k in ("CUDABROT_AMD_PASSES_PER_LAUNCH", "CUDABROT_AMD_NO_WORKSPACE", "CUDABROT_AMD_TWO_LEVEL"):
+            os.environ.pop(k, None)
+    return hist, int(status)
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -123,9 +171,18 @@ def main():
     n = 0
     last_print = time.time()
     while time.time() < t_end:
-        t = trial(rng)
+        t = renderer_trial(rng) if rng.random() < 0.3 else trial(rng)
         try:
-            if t["windows"]:
+            if "calls" in t:
+                got, status = render_with_renderer(t)
+                t["two_level"] = False
+                if t["windows"]:
+                    want = np.concatenate([render(t, cb.CB_KERNEL_SIMPLE, window=w)[0] for w in t["windows"]])
+                else:
+                    want = render(t, cb.CB_KERNEL_SIMPLE)[0]
+                wc = gc = {k: 0 for k in COMPARED}
+                gc = dict(gc, status=status)
+            elif t["windows"]:
                 got, gc = render(t, cb.CB_KERNEL_DEFAULT, fused=True)
                 singles = [render(t, cb.CB_KERNEL_SIMPLE, window=w) for w in t["windows"]]
                 want = np.concatenate([h for h, _ in singles])
