@@ -11,6 +11,8 @@ renderer), with / without scatter workspace (suggested or deliberately short), w
 and demands identical histograms and counters.
 
     python tools/gpu_fuzz.py [SECONDS] [SEED]      exit 1 at the first mismatch (the trial is printed)
+    HEAVY=1 python tools/gpu_fuzz.py ...           product-sized launches and canvases, deferred scatter
+                                                   against direct atomics of the same kernel
 """
 import os
 import random
@@ -63,7 +65,7 @@ def trial(rng):
     return t
 
 
-def render(t, variant, window=None, fused=False):
+def render(t, variant, window=None, fused=False, on_device=False):
     """window: (max, min) instead of the trial's; fused: all of t["windows"] in one launch (planes)."""
     dev = torch.device("cuda", 0)
     dims = cb.FractalDimensions.make(t["w"], t["h"], *t["box"])
@@ -113,7 +115,27 @@ def render(t, variant, window=None, fused=False):
     torch.cuda.synchronize()
     c = counters.cpu().numpy().view(np.uint64)
     cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in c)))
+    if on_device:
+        return hist, cnt
     return hist.cpu().numpy().view(np.uint64), cnt
+
+
+def heavy_trial(rng):
+    """Product-sized launches: the deferred scatter (one and two sort levels, carry) against the same
+    kernel with direct atomics -- the lock-step kernel would take minutes at these sizes."""
+    t = trial(rng)
+    t["w"] = rng.choice([1000, 4096, 6000, 9000, 12000])
+    t["h"] = rng.choice([1000, 4096, 6000, 9000])
+    if rng.random() < 0.6:
+        t["box"] = (-2.0, 2.0, -2.0, 2.0)
+    t["max_iter"] = rng.choice([100, 2000, 20000])
+    t["min_iter"] = rng.choice([0, 20, 20, 40])
+    t["threads"] = rng.choice([65536, 100000, 262144])
+    t["launch_samples"] = [rng.choice([50, 100, 400]) for _ in range(rng.randint(1, 3))]
+    t["workspace"] = rng.choice(["suggested", "suggested", "short"])
+    t["windows"] = None
+    t["heavy"] = True
+    return t
 
 
 def renderer_trial(rng):
@@ -171,9 +193,19 @@ def main():
     n = 0
     last_print = time.time()
     while time.time() < t_end:
-        t = renderer_trial(rng) if rng.random() < 0.3 else trial(rng)
+        if os.environ.get("HEAVY") == "1":
+            t = heavy_trial(rng)
+        else:
+            t = renderer_trial(rng) if rng.random() < 0.3 else trial(rng)
         try:
-            if "calls" in t:
+            if "heavy" in t:
+                got_d, gc = render(t, cb.CB_KERNEL_DEFAULT, on_device=True)
+                direct = dict(t, workspace="none", carry="none", two_level=False)
+                want_d, wc = render(direct, cb.CB_KERNEL_DEFAULT, on_device=True)
+                same = bool(torch.equal(got_d, want_d))
+                want, got = (np.zeros(1), np.zeros(1)) if same else (want_d.cpu().numpy(), got_d.cpu().numpy())
+                del got_d, want_d
+            elif "calls" in t:
                 got, status = render_with_renderer(t)
                 t["two_level"] = False
                 if t["windows"]:
@@ -207,6 +239,10 @@ def main():
                                                                      int(want.sum()), int(got.sum())), flush=True)
             return 1
         n += 1
+        if "heavy" in t:
+            print("  ok: %dx%d max_iter %d threads %d samples %r ws %s carry %s two_level %s" % (
+                t["w"], t["h"], t["max_iter"], t["threads"], t["launch_samples"], t["workspace"], t["carry"],
+                t["two_level"] or (t["w"] + 127) // 128 * ((t["h"] + 127) // 128) > 4096), flush=True)
         if time.time() - last_print > 30:
             print("%d trials identical so far" % n, flush=True)
             last_print = time.time()
