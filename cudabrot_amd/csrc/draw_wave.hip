@@ -205,11 +205,10 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   "v_lshlrev_b32 %[u], 4, " xp "\n\t"                    \
   "s_mov_b32 %[sc], " ck "\n\t"                          \
   "v_xor_b32 %[t], %[t], " xk "\n\t"                     \
-  "v_xor_b32 %[u], %[u], " xp "\n\t"                     \
   "v_lshlrev_b32 " xk ", 1, %[t]\n\t"                    \
-  "v_xor_b32 %[t], %[t], " xk "\n\t"                     \
-  "v_xor_b32 " xk ", %[u], %[t]\n\t"                     \
-  "v_add3_u32 " out ", v109, " xk ", %[sc]\n\t"
+  "v_bitop3_b32 %[u], %[u], " xp ", %[t] bitop3:0x96\n\t" \
+  "v_xor_b32 " xk ", %[u], " xk "\n\t"                   \
+  "v_add3_u32 " out ", " CB_V_D ", " xk ", %[sc]\n\t"
 // C = fma(fma(hi, 2^32, lo), 2^-50, 2^-50 - 4) with lo = o1, hi = o2 >> 11 (0x41f00000: the high word
 // of 2^32 as the literal of a VOP2 fmac)
 #define CB_XW_COORD(c)                                   \
@@ -217,7 +216,7 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   "v_lshrrev_b32 %[o2], 11, %[o2]\n\t"                   \
   "v_cvt_f64_u32 %[f], %[o2]\n\t"                        \
   "v_fmac_f64_e32 " c ", 0x41f00000, %[f]\n\t"           \
-  "v_fma_f64 " c ", " c ", %[k2m50], v[110:111]\n\t"
+  "v_fma_f64 " c ", " c ", %[k2m50], " CB_V_K "\n\t"
 // Four outputs and both coordinates; X0..X4 = the registers of the logical words x0..x4.
 #define CB_HEAD_DRAW(X0, X1, X2, X3, X4)                 \
   CB_XW_DRAW(X0, X4, "%[o1]", "0x587c5")                 \
@@ -225,7 +224,7 @@ __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
   CB_XW_COORD("%[cr]")                                   \
   CB_XW_DRAW(X2, X1, "%[o1]", "0x10974f")                \
   CB_XW_DRAW(X3, X2, "%[o2]", "0x161f14")                \
-  "v_add_u32 v109, %[sc], v109\n\t"                      \
+  "v_add_u32 " CB_V_D ", %[sc], " CB_V_D "\n\t"        \
   CB_XW_COORD("%[ci]")
 static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u == 0x10974fu &&
                   4u * 362437u == 0x161f14u,
@@ -242,7 +241,11 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 #define CB_V_X2 "v106"
 #define CB_V_X3 "v107"
 #define CB_V_X4 "v108"
-#define CB_HEAD_RESERVED "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
+#define CB_V_D "v109"
+#define CB_V_KLO "v110"
+#define CB_V_KHI "v111"
+#define CB_V_K "v[110:111]"
+#define CB_HEAD_RESERVED CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_D, CB_V_KLO, CB_V_KHI
 __device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci) {
   uint32_t t, u, o1, o2, sc, next;
   double f;
@@ -284,14 +287,14 @@ __device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci)
 // The reserved registers: load at the start of a launch (logical order, rot = 0) ...
 __device__ __forceinline__ void head_registers_load(const Xorwow &s) {
   asm volatile(
-      "v_mov_b32 v104, %[x0]\n\t"
-      "v_mov_b32 v105, %[x1]\n\t"
-      "v_mov_b32 v106, %[x2]\n\t"
-      "v_mov_b32 v107, %[x3]\n\t"
-      "v_mov_b32 v108, %[x4]\n\t"
-      "v_mov_b32 v109, %[d]\n\t"
-      "v_mov_b32 v110, 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
-      "v_mov_b32 v111, 0xc00fffff\n\t"
+      "v_mov_b32 " CB_V_X0 ", %[x0]\n\t"
+      "v_mov_b32 " CB_V_X1 ", %[x1]\n\t"
+      "v_mov_b32 " CB_V_X2 ", %[x2]\n\t"
+      "v_mov_b32 " CB_V_X3 ", %[x3]\n\t"
+      "v_mov_b32 " CB_V_X4 ", %[x4]\n\t"
+      "v_mov_b32 " CB_V_D ", %[d]\n\t"
+      "v_mov_b32 " CB_V_KLO ", 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
+      "v_mov_b32 " CB_V_KHI ", 0xc00fffff\n\t"
       :
       : [x0] "v"(s.x0), [x1] "v"(s.x1), [x2] "v"(s.x2), [x3] "v"(s.x3), [x4] "v"(s.x4), [d] "v"(s.d)
       : CB_HEAD_RESERVED);
@@ -300,12 +303,12 @@ __device__ __forceinline__ void head_registers_load(const Xorwow &s) {
 __device__ __forceinline__ Xorwow head_registers_read() {
   Xorwow s;
   asm volatile(
-      "v_mov_b32 %[x0], v104\n\t"
-      "v_mov_b32 %[x1], v105\n\t"
-      "v_mov_b32 %[x2], v106\n\t"
-      "v_mov_b32 %[x3], v107\n\t"
-      "v_mov_b32 %[x4], v108\n\t"
-      "v_mov_b32 %[d], v109\n\t"
+      "v_mov_b32 %[x0], " CB_V_X0 "\n\t"
+      "v_mov_b32 %[x1], " CB_V_X1 "\n\t"
+      "v_mov_b32 %[x2], " CB_V_X2 "\n\t"
+      "v_mov_b32 %[x3], " CB_V_X3 "\n\t"
+      "v_mov_b32 %[x4], " CB_V_X4 "\n\t"
+      "v_mov_b32 %[d], " CB_V_D "\n\t"
       : [x0] "=v"(s.x0), [x1] "=v"(s.x1), [x2] "=v"(s.x2), [x3] "=v"(s.x3), [x4] "=v"(s.x4),
         [d] "=v"(s.d));
   return s;
@@ -498,7 +501,21 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
   "v_cmp_nlt_f64_e64 %[c0], %[k16], %[a0]\n\t"            \
   "v_cmp_nlt_f64_e64 %[c1], %[k16], %[a1]\n\t"
 #define CB_STEP2X4 CB_STEP2 CB_STEP2 CB_STEP2 CB_STEP2
-#define CB_STEP2X32 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+#define CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+#if CB_CHUNK == 24
+#define CB_STEP2_CHUNK CB_STEP2X24
+#elif CB_CHUNK == 30
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2 CB_STEP2
+#elif CB_CHUNK == 32
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2X4
+#elif CB_CHUNK == 36
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+#else
+#error "unroll CB_STEP2 for this chunk length"
+#endif
+#define CB_STR2(x) #x
+#define CB_STR(x) CB_STR2(x)
+#define CB_CHUNK_S CB_STR(CB_CHUNK)  // the chunk length as an inline constant of the asm blocks below
 
 // kChunk steps on orbit A of the lanes in mask_a and on orbit B of the lanes in mask_b (both
 // wave-uniform; called with EXEC = all 64 lanes).  esc_a / esc_b receive the lanes whose orbit
@@ -507,7 +524,6 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
 __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsigned long long mask_b,
                                                Orbit &oa, Orbit &ob, unsigned long long &esc_a,
                                                unsigned long long &esc_b, uint32_t &lane_steps) {
-  static_assert(kChunk == 32, "CB_STEP2X32 is unrolled for 32 steps");
   unsigned long long la = mask_a, lb = mask_b, c0, c1;
   uint32_t cnt, t0, t1;
   double a0, a1;
@@ -516,7 +532,7 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
       "s_mov_b32 %[cnt], 0\n\t"
       "s_mov_b64 %[c0], -1\n\t"
       "s_mov_b64 %[c1], -1\n\t"
-      CB_STEP2X32
+      CB_STEP2_CHUNK
       "s_and_b64 %[la], %[la], %[c0]\n\t"
       "s_and_b64 %[lb], %[lb], %[c1]\n\t"
       : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [la] "+s"(la),
@@ -540,7 +556,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
                                             uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
                                             uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
                                             unsigned long long &full, unsigned long long &tail) {
-  static_assert(kQ1Cap == 96 && kChunk == 32, "ring length, plane distances and chunk length below");
+  static_assert(kQ1Cap == 96 && kChunk <= 64, "ring length and plane distances below; chunk length as an inline constant");
   unsigned long long save;
   uint32_t n, rank, slot, t;
   asm volatile(
@@ -567,7 +583,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "v_mov_b32 %[lrem], %[ls]\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "1:\n\t"
-      "v_cmp_le_u32_e64 %[full], 32, %[lrem]\n\t"
+      "v_cmp_le_u32_e64 %[full], " CB_CHUNK_S ", %[lrem]\n\t"
       "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
@@ -579,7 +595,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
 }
 
 #define CB_RETIRE_SURVIVORS                                \
-      "v_subrev_u32 %[lrem], 32, %[lrem]\n\t"            \
+      "v_subrev_u32 %[lrem], " CB_CHUNK_S ", %[lrem]\n\t" \
       "v_cmp_eq_u32_e64 %[ended], 0, %[lrem]\n\t"        \
       "s_cmp_eq_u32 %[chkf], 0\n\t"                      \
       "s_cbranch_scc1 2f\n\t"                            \
@@ -599,13 +615,11 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "s_andn2_b64 exec, exec, %[per]\n\t"
 #define CB_RETIRE_TAIL                                     \
       "v_sub_u32 %[t], %[ls], %[lrem]\n\t"               \
-      "v_lshrrev_b32 %[t], 5, %[t]\n\t"                  \
-      "v_ffbh_u32 %[slot], %[t]\n\t"                     \
-      "v_sub_u32 %[slot], %[kbits], %[slot]\n\t"         \
-      "v_max_i32 %[slot], 0, %[slot]\n\t"                \
-      "v_lshrrev_b32 %[t2], %[slot], %[t]\n\t"           \
-      "v_lshlrev_b32 %[t2], %[slot], %[t2]\n\t"          \
-      "v_cmpx_eq_u32_e32 vcc, %[t], %[t2]\n\t"           \
+      "v_cvt_f32_u32 %[t], %[t]\n\t"                     \
+      "v_mul_f32 %[t], %[invl], %[t]\n\t"                \
+      "v_rndne_f32 %[t], %[t]\n\t"                       \
+      "v_and_b32 %[t], %[kmask], %[t]\n\t"               \
+      "v_cmpx_eq_u32_e32 vcc, 0, %[t]\n\t"               \
       "v_mov_b64 %[sr], %[r]\n\t"                        \
       "v_mov_b64 %[si], %[i]\n\t"                        \
       "3:\n\t"                                           \
@@ -654,16 +668,20 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
                                             uint32_t check_periodic, uint32_t q2_tail, uint32_t q2_lds,
                                             unsigned long long &push, unsigned long long &ended,
                                             unsigned long long &periodic) {
-  static_assert(kQ2Cap == 192 && kChunk == 32, "ring length, plane distance and chunk length below");
+  static_assert(kQ2Cap == 192 && kChunk <= 64, "ring length and plane distance below; chunk length as an inline constant");
+  static_assert(kBrentBits >= 1 && kBrentBits <= 8, "bits of the chunk count kept by the save schedule");
   unsigned long long save;
-  uint32_t slot, t, t2;
+  uint32_t slot, t;
+  // chunks done = steps done / kChunk, exactly, as a float (a few thousand at most): the count has no set
+  // bit below its top kBrentBits iff the float's mantissa is zero below its top kBrentBits - 1 bits
+  const float inv_chunk = 1.0f / (float) kChunk;
+  const uint32_t low_mantissa = (1u << (24 - kBrentBits)) - 1u;
 #define CB_RETIRE_OPERANDS                                                                                   \
   : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),      \
     [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic), [save] "=&s"(save), [slot] "=&v"(slot), \
-    [t2] "=&v"(t2),                                                                                          \
     [t] "=&v"(t)                                                                                             \
   : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),       \
-    [chkf] "s"(check_periodic), [kbits] "s"(32u - kBrentBits),                                               \
+    [chkf] "s"(check_periodic), [invl] "s"(inv_chunk), [kmask] "s"(low_mantissa),                            \
     [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)                             \
   : "vcc", "scc", "memory"
   asm volatile(CB_RETIRE_ESCAPED CB_RETIRE_SURVIVORS CB_RETIRE_TAIL CB_RETIRE_OPERANDS);

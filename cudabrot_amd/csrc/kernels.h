@@ -140,7 +140,8 @@ hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
 hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stream);
 
 // Steps per chunk of the LONG stage; the stage split is chosen so that no chunk straddles min_iter.
-constexpr int kChunk = 32;
+#define CB_CHUNK 32
+constexpr int kChunk = CB_CHUNK;
 void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps);
 
 }  // namespace cb
