@@ -18,7 +18,7 @@
 //           this is where the many orbits that leave after a few dozen iterations leave.  mid_steps
 //           is chosen so that min_iter - (head_steps + mid_steps) is a multiple of kChunk.
 //           Survivors (~2 % of the samples) go to Q1 as (c, z).
-//   LONG    each lane holds TWO deep orbits and iterates them side by side in chunks of kChunk (32)
+//   LONG    each lane holds TWO deep orbits and iterates them side by side in chunks of kChunk (30)
 //           steps of hand-written asm; finished slots refill from Q1 at chunk boundaries, so the lanes
 //           stay on deep orbits.  An orbit is retired when it escapes, reaches max_iter, or is found
 //           to be exactly periodic (then it can never escape).  Escaped orbits whose chunk lies at or
@@ -653,7 +653,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
 //   escaped lanes    l_rem = 0; those whose chunk lies at or above min_iter (l_rem <= accept_rem, the
 //                    chunk being on one side of min_iter, cudabrot.cu:407-408) push c to Q2 -- ring slot
 //                    (q2_tail + rank) mod 192 at q2_lds, q2_ci 1536 bytes on: `push`
-//   the others       l_rem -= 32; `ended`: reached max_iter (IterateMandelbrot returns max,
+//   the others       l_rem -= kChunk; `ended`: reached max_iter (IterateMandelbrot returns max,
 //                    cudabrot.cu:339); `periodic` (check_periodic != 0 only): z is bit for bit the saved
 //                    point, so the orbit repeats for ever and can never escape -- retired with the
 //                    remaining iterations added to skip (two 32-bit halves); else Brent's schedule,
@@ -661,7 +661,8 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
 //                    kBrentBits = 2 (1, 1.5, 2, 3, 4, 6 ... chunks).  The saved point must be older than
 //                    the cycle is long, yet young enough to lie on the cycle: measured at C3, this
 //                    schedule executes 3 % fewer iterations than powers of two alone, and keeping the
-//                    top three bits 8 % more
+//                    top three bits 8 % more.  (Two saved points replaced in turn cut another 4 %, but
+//                    their 8 registers end the co-residency with the scatter's count kernels: slower.)
 __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, double &seen_i, int &l_rem,
                                             uint32_t &skip_lo, uint32_t &skip_hi, unsigned long long ran,
                                             unsigned long long esc, int accept_rem, uint32_t long_steps,
@@ -1343,8 +1344,8 @@ draw_wave_kernel(DrawArgs a) {
         // ever and every point of it passed the escape test: the sample can never escape, so
         // IterateMandelbrot would return max_iterations -- the same outcome, without executing the
         // remaining iterations.  Brent's scheme at chunk granularity: compare with one saved point,
-        // re-save when the chunk count is a power of two; a cycle of period p is found at most
-        // kChunk * p iterations after it has begun.
+        // re-save on a geometric schedule of chunk counts (long_retire); a cycle of period p is found
+        // p / gcd(p, kChunk) chunks after a save that lies on it (hence kChunk = 30, kernels.h).
 #pragma unroll
         for (int o = 0; o < kOrbitsPerLane; ++o) {
           unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
