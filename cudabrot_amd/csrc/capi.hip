@@ -77,6 +77,8 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.inv_delta_imag = 0.0;
   a.pow2_real = exact_reciprocal(dims->delta_real, &a.inv_delta_real) ? 1 : 0;
   a.pow2_imag = exact_reciprocal(dims->delta_imag, &a.inv_delta_imag) ? 1 : 0;
+  a.rcp_delta_real = 1.0 / dims->delta_real;  // only ever an estimate: any value (inf, nan) is safe
+  a.rcp_delta_imag = 1.0 / dims->delta_imag;
   a.w = dims->w;
   a.h = dims->h;
   a.max_iter = it->max_escape_iterations;

@@ -152,6 +152,7 @@ struct Canvas {
   double inv_delta_real, inv_delta_imag;  // valid iff pow2_real / pow2_imag
   int w, h;
   int pow2_real, pow2_imag;  // delta is a power of two: x / delta == x * (1/delta) bit for bit
+  double rcp_delta_real, rcp_delta_imag;  // RN(1 / delta), an estimate only (DrawArgs)
 };
 
 // IncrementPixelCounter, cudabrot.cu:302-314, with the += made a device-scope atomic (the

@@ -18,6 +18,8 @@ __device__ __forceinline__ Canvas make_canvas(const DrawArgs &a) {
   c.h = a.h;
   c.pow2_real = a.pow2_real;
   c.pow2_imag = a.pow2_imag;
+  c.rcp_delta_real = a.rcp_delta_real;
+  c.rcp_delta_imag = a.rcp_delta_imag;
   return c;
 }
 

@@ -704,7 +704,14 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 //                       and, scaling being exact, equals the single fma(R, 0.5/d, -min_re/d);
 //   CB_REPLAY_BIN_DIV   else the correctly rounded IEEE quotient by the instruction sequence hipcc
 //                       emits for a double division (v_div_scale / v_rcp / Newton steps /
-//                       v_div_fmas / v_div_fixup).
+//                       v_div_fmas / v_div_fixup) -- but only when it can matter.  Only trunc(q) of the
+//                       quotient q = RN(a / d) is used.  The estimate q' = RN(a * RN(1/d)) is within
+//                       q * 2^-51 of q, so below 2^22 the two lie less than 2^-29 apart, and when the
+//                       fraction of q' is inside (2^-24, 1 - 2^-24) no integer lies between them:
+//                       trunc(q') = trunc(q).  From 2^22 on both are beyond any canvas the stream can
+//                       describe (sides <= 65536), whatever the conversion yields.  If any lane of the
+//                       step fails the test (|fract(q') - 1/2| < 1/2 - 2^-24; a NaN or infinite estimate
+//                       fails it too) the whole wave takes the exact division: about one step in 10^7.
 // The tests re >= min_re, im >= min_im are made on the doubled values (R >= 2 min_re).  The hits of a
 // step are compacted with v_mbcnt and stored side by side (one coalesced store).  The stream word is
 // row << rsh | col | tag (one channel: rsh = 16, tag = 0; fused channels: the orbit's channel set above
@@ -728,7 +735,22 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 #define CB_REPLAY_BIN_DIV                                 \
   "v_fma_f64 %[fx], %[r], 0.5, -%[ox]\n\t"                \
   "v_fma_f64 %[fy], %[i], 0.5, -%[oy]\n\t"                \
-  CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]")
+  "v_mul_f64 %[d0], %[fx], %[rx]\n\t"                     \
+  "v_mul_f64 %[d1], %[fy], %[ry]\n\t"                     \
+  "v_fract_f64 %[d2], %[d0]\n\t"                          \
+  "v_fract_f64 %[d3], %[d1]\n\t"                          \
+  "v_add_f64 %[d2], %[d2], -0.5\n\t"                      \
+  "v_add_f64 %[d3], %[d3], -0.5\n\t"                      \
+  "v_cmp_nlt_f64_e64 %[scp], |%[d2]|, %[kg]\n\t"          \
+  "v_cmp_nlt_f64_e64 vcc, |%[d3]|, %[kg]\n\t"             \
+  "s_or_b64 %[scp], %[scp], vcc\n\t"                      \
+  "s_cbranch_scc0 4f\n\t"                                 \
+  CB_DIV("%[fx]", "%[fx]", "%[sx]") CB_DIV("%[fy]", "%[fy]", "%[sy]") \
+  "s_branch 5f\n\t"                                       \
+  "4:\n\t"                                                \
+  "v_mov_b64 %[fx], %[d0]\n\t"                            \
+  "v_mov_b64 %[fy], %[d1]\n\t"                            \
+  "5:\n\t"
 
 #define CB_REPLAY_HEAD                                    \
   "s_mov_b64 %[save], exec\n\t"                           \
@@ -821,6 +843,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   } else {
     const double sx = uniform_f64(cv.delta_real), sy = uniform_f64(cv.delta_imag);
     const double ox = uniform_f64(cv.min_real), oy = uniform_f64(cv.min_imag);
+    const double rx = uniform_f64(cv.rcp_delta_real), ry = uniform_f64(cv.rcp_delta_imag);
+    const double kg = 0.5 - 0x1p-24;
     asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
@@ -830,6 +854,7 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
                  : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
                    [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
                    [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");

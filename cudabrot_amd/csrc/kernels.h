@@ -82,6 +82,8 @@ struct DrawArgs {
   // canvas (cudabrot.cu:46-58) + exact-reciprocal fast path
   double min_real, min_imag, delta_real, delta_imag, inv_delta_real, inv_delta_imag;
   int w, h, pow2_real, pow2_imag;
+  // RN(1 / delta) for any delta: the replay burst's quotient estimate (draw_wave.hip, CB_REPLAY_BIN_EST)
+  double rcp_delta_real, rcp_delta_imag;
   // iteration control (cudabrot.cu:62-67)
   int max_iter, min_iter;
   // stage split of draw_wave_kernel (plan_stages): HEAD runs iterations [0, head_steps), MID the
