@@ -105,7 +105,7 @@ const char kUsageBody[] =
 
 // ---- argument table ----------------------------------------------------------------------------
 
-enum class Value { kNone, kInt, kDouble, kText };
+enum class Value { kNone, kInt, kLong, kDouble, kText };  // kInt: truncated to int like the reference's flags
 
 struct Flag {
   const char *name;
@@ -179,7 +179,7 @@ const std::vector<Flag> &flag_table() {
        [](Settings &s, long i, double, const char *) { s.gpus = (i < 1) ? 1 : (i > 64 ? 64 : (int) i); }},
       {"--burning-ship", Value::kNone, nullptr, false,
        [](Settings &s, long, double, const char *) { s.burning_ship = true; }},
-      {"--seed", Value::kInt, nullptr, false,
+      {"--seed", Value::kLong, nullptr, false,  // the generator's seed is 64 bits wide (rocrand_init)
        [](Settings &s, long i, double, const char *) { s.seed = (uint64_t) i; }},
       {"--rng-state", Value::kText, nullptr, false,
        [](Settings &s, long, double, const char *t) { s.rng_state_file = t; }},
@@ -240,6 +240,8 @@ Settings parse_arguments(int argc, char **argv) {
         char *end = nullptr;
         if (flag->value == Value::kInt) {
           as_int = (int) strtol(text, &end, 10);  // truncated to int like the reference
+        } else if (flag->value == Value::kLong) {
+          as_int = (long) strtoull(text, &end, 10);
         } else {
           as_double = strtod(text, &end);
         }

@@ -141,11 +141,12 @@ def test_gpus_flag_shards_the_subsequences_and_sums_once(exe, oracle, tmp_path):
     assert stats["samples"] == cnt["samples"] and stats["increments"] == cnt["increments"] and stats["status"] == 0
 
 
-def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path):
+@pytest.mark.parametrize("seed", [4242, 123456789012345])   # the generator's seed is 64 bits wide
+def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path, seed):
     buf = str(tmp_path / "seed.bin")
-    r = run(exe, "--passes", "1", "--seed", "4242", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
+    r = run(exe, "--passes", "1", "--seed", str(seed), "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
     assert r.returncode == 0
-    hist, _ = oracle.render(300, 200, 200, 20, T, 1, seed=4242, omp_threads=0)
+    hist, _ = oracle.render(300, 200, 200, 20, T, 1, seed=seed, omp_threads=0)
     assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
 
 
