@@ -154,6 +154,7 @@ def _load():
         "cb_renderer_create_channels": (i32, [C.POINTER(vp), i32, dims_p, it_p, i32, u64, u64, u32]),
         "cb_renderer_grayscale_plane": (i32, [vp, i32, C.c_double, i32, vp, C.POINTER(u64), C.POINTER(C.c_double)]),
         "cb_renderer_render_passes": (i32, [vp, u32, i32]),
+        "cb_renderer_prepare": (i32, [vp, i32]),
         "cb_renderer_read_histogram": (i32, [vp, vp]),
         "cb_renderer_write_histogram": (i32, [vp, vp]),
         "cb_renderer_read_counters": (i32, [vp, cnt_p]),
@@ -185,7 +186,8 @@ EXPORTED_SYMBOLS = (
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
     "cb_renderer_destroy cb_set_grayscale_pixels cb_save_image cb_save_image_be cb_tone_value "
     "cb_tone_map_device cb_renderer_grayscale_image cb_renderer_read_rng_states cb_renderer_write_rng_states "
-    "cb_draw_buddhabrot_channels cb_flush_scatter_channels cb_renderer_create_channels cb_renderer_grayscale_plane cb_renderers_reduce"
+    "cb_draw_buddhabrot_channels cb_flush_scatter_channels cb_renderer_create_channels cb_renderer_grayscale_plane cb_renderers_reduce "
+    "cb_renderer_prepare"
 ).split()
 
 
@@ -270,6 +272,10 @@ class Renderer:
                                                 first_subsequence, n_threads),
                 "cb_renderer_create_channels",
             )
+
+    def prepare(self, kernel_variant=CB_KERNEL_DEFAULT):
+        """Allocate now what the first render_passes would (the scatter workspaces)."""
+        _check(lib.cb_renderer_prepare(self._h, kernel_variant), "cb_renderer_prepare")
 
     def render_passes(self, passes, kernel_variant=CB_KERNEL_DEFAULT):
         _check(lib.cb_renderer_render_passes(self._h, passes, kernel_variant), "cb_renderer_render_passes")

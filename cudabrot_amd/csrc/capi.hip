@@ -462,15 +462,21 @@ int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_
   return 0;
 }
 
-int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant) {
-  if (!r) return (int) hipErrorInvalidValue;
-  CB_TRY(hipSetDevice(r->device));
-  // 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
-  static const uint32_t max_passes_per_launch = [] {
+namespace {
+
+// 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
+uint32_t max_passes_per_launch() {
+  static const uint32_t v = [] {
     const char *e = getenv("CUDABROT_AMD_PASSES_PER_LAUNCH");  // experiment knob
-    const long v = e ? atol(e) : 0;
-    return (v >= 1 && v <= 4096) ? (uint32_t) v : kRendererPassesPerLaunch;
+    const long n = e ? atol(e) : 0;
+    return (n >= 1 && n <= 4096) ? (uint32_t) n : kRendererPassesPerLaunch;
   }();
+  return v;
+}
+
+// What a renderer allocates on first use, because it depends on the kernel variant: the two scatter
+// workspaces (tens of GB on a large canvas -- hipMalloc of that size can take seconds).
+void prepare_for_variant(cb_renderer *r, int kernel_variant) {
   if ((kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") &&
       !g_wave_dump) {
     const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
@@ -480,10 +486,10 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
   }
   if (!r->workspace_tried && (kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) != CB_KERNEL_SIMPLE &&
       getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
-    // scatter workspace for the largest launch this call makes; on any failure: direct atomics
+    // scatter workspace for the largest launch render_passes makes; on any failure: direct atomics
     r->workspace_tried = 1;
     size_t want = cb_scatter_workspace_bytes(&r->dims, r->n_threads,
-                                             max_passes_per_launch * CB_SAMPLES_PER_THREAD);
+                                             max_passes_per_launch() * CB_SAMPLES_PER_THREAD);
     size_t free_b = 0, total_b = 0;
     if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       if (want > free_b / 4) want = free_b / 4;
@@ -498,6 +504,22 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
       }
     }
   }
+}
+
+}  // namespace
+
+int cb_renderer_prepare(cb_renderer *r, int kernel_variant) {
+  if (!r) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  prepare_for_variant(r, kernel_variant);
+  return (int) hipDeviceSynchronize();
+}
+
+int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant) {
+  if (!r) return (int) hipErrorInvalidValue;
+  CB_TRY(hipSetDevice(r->device));
+  const uint32_t max_passes_per_launch = ::max_passes_per_launch();
+  prepare_for_variant(r, kernel_variant);
   if (r->carry_pending && r->carry_variant != kernel_variant) {
     int rc = finish(r);  // a different kernel variant cannot take over the carried work
     if (rc) return rc;

@@ -535,8 +535,11 @@ class Run {
       }
     }
     fflush(stdout);
-    const double t0 = wall_seconds();
     const int variant = cfg_.kernel_variant | (cfg_.burning_ship ? CB_KERNEL_FLAG_BURNING_SHIP : 0);
+    // what the reference allocates in SetupCUDA, before its clock starts (cudabrot.cu:153-189,476)
+    CB_CHECK(cb_renderer_prepare(renderer_, variant));
+    for (cb_renderer *p : peers_) CB_CHECK(cb_renderer_prepare(p, variant));
+    const double t0 = wall_seconds();
     // the pass loop of one rank; every rank follows the same clock / pass budget
     auto pass_loop = [&](cb_renderer *r) -> long {
       const double launch_seconds = 0.2;

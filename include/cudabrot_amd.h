@@ -195,6 +195,10 @@ int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_
  * carried to the next call; cb_renderer_finish (called by the read/write functions below) completes
  * them. */
 int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant);
+/* Optional, before the first cb_renderer_render_passes: allocates now what that call would allocate for
+ * this kernel variant (the scatter workspaces: tens of GB on a large canvas), so that a caller who times
+ * the pass loop -- like the reference's "passes took" line, cudabrot.cu:499-500 -- does not time hipMalloc. */
+int cb_renderer_prepare(cb_renderer *r, int kernel_variant);
 /* Completes all carried work: afterwards the device histogram and counters account for every sample
  * of every pass rendered so far (needed before using cb_renderer_device_histogram directly). */
 int cb_renderer_finish(cb_renderer *r);

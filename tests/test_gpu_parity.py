@@ -480,3 +480,22 @@ def test_rccl_reduce_calls_on_one_rank(cb, oracle, monkeypatch):
         got = r.read_histogram()
     ref, _ = oracle.render(256, 192, 300, 20, 4096, 2)
     assert np.array_equal(got, ref)
+
+
+def test_renderer_prepare_allocates_ahead_and_changes_nothing(cb, oracle):
+    """cb_renderer_prepare: the scatter workspaces are allocated before the (timed) pass loop instead of
+    inside its first call; optional, repeatable, and without effect on the result."""
+    w, h, t, passes = 320, 200, 4096, 3
+    dims = cb.FractalDimensions.make(w, h)
+    ref, rc = oracle.render(w, h, 300, 20, t, passes)
+    with cb.Renderer(dims, cb.IterationControl(300, 20), n_threads=t) as r:
+        r.prepare()
+        r.prepare()
+        r.render_passes(passes)
+        got = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    assert np.array_equal(got, ref) and cnt["status"] == 0 and cnt["increments"] == rc["increments"]
+    with cb.Renderer(dims, cb.IterationControl(300, 20), n_threads=t) as r:
+        r.prepare(cb.CB_KERNEL_SIMPLE)          # the lock-step kernel needs no workspace
+        r.render_passes(passes, cb.CB_KERNEL_SIMPLE)
+        assert np.array_equal(r.read_histogram(), ref)
