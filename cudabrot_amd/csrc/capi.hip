@@ -309,7 +309,14 @@ size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_
   if (!dims || dims->w <= 0 || dims->h <= 0 || n_threads == 0 || samples_per_thread == 0) return 0;
   const uint32_t n_waves = cb::draw_wave_count(n_threads);
   const double entries = (double) n_threads * (double) samples_per_thread * kEntriesPerSample;
-  return cb::bin_workspace_bytes(dims->w, dims->h, n_waves, entries / n_waves);
+  // large enough for a fused launch of up to CB_MAX_CHANNELS planes too (their tiles are sorted as one
+  // canvas: a longer count matrix, the same stream)
+  size_t best = 0;
+  for (int planes = 1; planes <= CB_MAX_CHANNELS; ++planes) {
+    const size_t b = cb::bin_workspace_bytes(dims->w, dims->h, n_waves, entries / n_waves, planes);
+    if (b > best) best = b;
+  }
+  return best;
 }
 
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
@@ -401,16 +408,11 @@ int cb_flush_scatter_channels(const cb_fractal_dimensions *dims, cb_pixel *d_his
   if (!dims || !d_hist || dims->w <= 0 || dims->h <= 0 || n_channels < 1 || n_channels > CB_MAX_CHANNELS) {
     return (int) hipErrorInvalidValue;
   }
-  cb::BinLayout b = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
-                                        cb::draw_wave_count(n_threads), n_channels);
-  const size_t plane = (size_t) dims->w * (size_t) dims->h;
-  for (int j = 0; j < n_channels; ++j) {  // one pass over the stream per channel: the words tagged with it
-    b.channel = j;
-    const hipError_t e = cb::launch_binned_scatter(b, reinterpret_cast<unsigned long long *>(d_hist) + plane * j,
-                                                   dims->w, dims->h, reinterpret_cast<hipStream_t>(stream));
-    if (e != hipSuccess) return (int) e;
-  }
-  return 0;
+  // every word carries the index of its plane and the planes are sorted as one canvas: one pass
+  const cb::BinLayout b = cb::make_bin_layout(d_workspace, workspace_bytes, dims->w, dims->h,
+                                              cb::draw_wave_count(n_threads), n_channels);
+  return (int) cb::launch_binned_scatter(b, reinterpret_cast<unsigned long long *>(d_hist), dims->w, dims->h,
+                                         reinterpret_cast<hipStream_t>(stream));
 }
 
 int cb_renderer_create(cb_renderer **out, int device, const cb_fractal_dimensions *dims,

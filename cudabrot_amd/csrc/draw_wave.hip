@@ -714,7 +714,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 //                       fails it too) the whole wave takes the exact division: about one step in 10^7.
 // The tests re >= min_re, im >= min_im are made on the doubled values (R >= 2 min_re).  The hits of a
 // step are compacted with v_mbcnt and stored side by side (one coalesced store).  The stream word is
-// row << rsh | col | tag (one channel: rsh = 16, tag = 0; fused channels: the orbit's channel set above
+// row << rsh | col | tag (one channel: rsh = 16, tag = 0; fused channels: the index of the pass's channel above
 // row and col), and only the lanes of `emit` write (fused channels: not the lanes still measuring
 // their escape index).
 #define CB_REPLAY_BIN_POW2                                \
@@ -945,31 +945,32 @@ draw_wave_kernel(DrawArgs a) {
   int p_steps = 0;
   // Fused channels (DrawArgs::n_channels > 0): an orbit popped from Q2 is first replayed WITHOUT
   // recording (p_real = false) -- the stages before know its escape index only to a chunk -- and, once
-  // the index k is known, a second time with the set of channels whose window holds k as its tag.
+  // the index k is known, once more for every channel whose window holds k, with that channel's index
+  // as the tag of its words (above row and col; the scatter sorts the planes as one canvas).
   const bool multi = a.n_channels > 0;
   bool p_real = true;
   uint32_t p_tag = 0u;
-  // lanes of `finished` have just ended a replay pass
+  // lanes of `finished` have just ended a replay pass: the measuring one (then the orbit's channels are
+  // known) or a recorded one (then the next of its channels follows, if any -- windows may overlap)
   auto channel_decision = [&](unsigned long long finished) {
     const bool fin = lane_in(finished);
     uint32_t set = 0u;
-    if (fin && !p_real) {
+    if (fin) {
       const int k = p_steps - 1;  // index of the escaping iteration (cudabrot.cu:336)
       for (int j = 0; j < a.n_channels; ++j) {
         if (k >= a.chan_min[j] && k < a.chan_max[j]) set |= 1u << j;
       }
+      if (p_real) set &= ~((2u << (p_tag >> a.bin.e_chan_shift)) - 1u);  // the channels still to come
     }
-    const bool again = fin && !p_real && set != 0u;
-    const unsigned long long again_mask = __ballot(again);
-    const unsigned long long drop_mask = __ballot(fin && !p_real && set == 0u);
-    n_recorded += (unsigned long long) __popcll(again_mask);
-    n_too_fast += (unsigned long long) __popcll(drop_mask);  // in no window (cudabrot.cu:407-408 for every channel)
-    if (again) {  // second pass: the same orbit from z = c, recorded
+    const bool measured = fin && !p_real;
+    n_recorded += (unsigned long long) __popcll(__ballot(measured && set != 0u));
+    n_too_fast += (unsigned long long) __popcll(__ballot(measured && set == 0u));  // in no window (cudabrot.cu:407-408 for every channel)
+    if (fin && set != 0u) {  // another pass: the same orbit from z = c, recorded into its next channel
       po.r = po.cr;
       po.i = po.ci;
       p_steps = 0;
       p_real = true;
-      p_tag = set << a.bin.e_chan_shift;
+      p_tag = (uint32_t) (__ffs((int) set) - 1) << a.bin.e_chan_shift;
       p_act = true;
     }
   };
@@ -1123,15 +1124,9 @@ draw_wave_kernel(DrawArgs a) {
 #endif
             hit = p_real && pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);  // cudabrot.cu:308-311 (halving is exact)
             if (hit) {                                                 // cudabrot.cu:312
-              if (!multi) {
-                add_to_pixel(a.hist, cv, row, col, 1ull);
-              } else {
-                for (int j = 0; j < a.n_channels; ++j) {
-                  if ((p_tag >> (a.bin.e_chan_shift + (uint32_t) j)) & 1u) {
-                    add_to_pixel(a.hist + (unsigned long long) j * a.plane_pixels, cv, row, col, 1ull);
-                  }
-                }
-              }
+              // fused channels: the plane of the channel this pass records into
+              add_to_pixel(a.hist + (unsigned long long) (p_tag >> a.bin.e_chan_shift) * a.plane_pixels, cv, row,
+                           col, 1ull);
             }
             p_steps++;
             done = m4 > 16.0;                                          // cudabrot.cu:363

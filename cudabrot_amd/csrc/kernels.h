@@ -37,7 +37,7 @@ struct BinLayout {
   uint32_t enabled;     // 0: REPLAY adds to the histogram directly
   uint32_t n_waves;     // regions in the stream (= waves of the draw kernel)
   uint32_t cap;         // entries per wave region (multiple of 4)
-  uint32_t n_tiles;     // tiles_x * tiles_y
+  uint32_t n_tiles;     // n_planes * tiles_x * tiles_y
   uint32_t tiles_x;
   uint32_t slice_entries;  // entries one accumulate workgroup takes
   // more than kMaxTiles tiles: the stream is first partitioned into groups of 1024 tiles (level A),
@@ -47,14 +47,17 @@ struct BinLayout {
   uint32_t max_regions;   // size of the region table (level B; = n_waves with one level)
   uint32_t count_stride;  // row length of `count`
   // Layout of a stream word: col in the low bits, row above it (e_row_shift), and -- fused multi-channel
-  // renders only -- the set of channels the orbit belongs to above both (e_chan_shift).  One channel:
-  // row << 16 | col.  `channel` (>= 0) makes a flush take only the words whose set holds that channel.
-  uint32_t e_row_shift, e_col_mask, e_row_mask, e_chan_shift;
-  int channel;
+  // renders only -- the index of the channel (plane) the point goes to above both (e_chan_shift,
+  // e_chan_mask; 0 / 0 with one plane).  One channel: row << 16 | col.  The planes are sorted as ONE
+  // canvas of n_planes * tiles_y tile rows: tile index = (plane * tiles_y + tile row) * tiles_x + tile
+  // column, n_tiles = n_planes * tiles_x * tiles_y, so one count -> sort -> accumulate serves all planes.
+  uint32_t e_row_shift, e_col_mask, e_row_mask, e_chan_shift, e_chan_mask;
+  uint32_t n_planes, tiles_y;
+  unsigned long long plane_pixels;  // w * h: distance between the planes of the histogram
   uint32_t *wave_count;           // [n_waves]            entries written by each wave
   uint32_t *stream;               // [n_waves][cap]       packed row << 16 | col
-  uint32_t *a_count;              // [n_groups*16][n_waves]  level A counts, then prefix over waves
-  unsigned long long *a_base;     // [n_groups*16 + 1]    level A exclusive prefix over keys
+  uint32_t *a_count;              // [n_groups*replicas][n_waves]  level A counts, then prefix over waves
+  unsigned long long *a_base;     // [n_groups*replicas + 1]  level A exclusive prefix over keys
   uint32_t *grouped;              // [n_waves * cap]      the stream, grouped (two levels)
   unsigned long long *region_start;  // [max_regions]     regions of the (grouped) stream ...
   uint32_t *region_count;         // [max_regions]
@@ -69,8 +72,8 @@ struct BinLayout {
 };
 
 // Bytes of a workspace for launches that write about entries_per_wave stream entries per wave (0 if
-// the canvas cannot use one: a side above 65536 or more than 65536 tiles).
-size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave);
+// the canvas cannot use one: a side above 65536 or more than 262144 tiles over all planes).
+size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave, int n_planes = 1);
 // Carves `bytes` at `workspace` into a BinLayout (enabled = 0 if it is too small or the canvas does
 // not qualify).
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves, int n_channels = 0);

@@ -17,7 +17,7 @@
 //              slice, then added to the u64 histogram with coalesced device-scope atomics.  Hot
 //              tiles are many slices, so the grid stays balanced.
 //
-// Two levels (up to 65536 tiles: 20000 x 20000 and beyond).  With more tiles than LDS counters, or
+// Two levels (up to 262144 tiles: 20000 x 20000 and beyond).  With more tiles than LDS counters, or
 // runs too short to coalesce, the stream is first partitioned into GROUPS of 1024 consecutive
 // tiles by the same count -> scan -> scatter (level A: the key is group * 16 + a lane-derived
 // replica, which spreads the LDS atomics over 4 counters per group; whole 4-byte entries are
@@ -45,22 +45,21 @@ constexpr uint32_t kAccThreads = 512;
 constexpr uint32_t kGroupTiles = 1024;             // tiles per group (two levels)
 constexpr uint32_t kGroupShift = 10;
 constexpr uint32_t kReplicas = 4;                  // level-A keys per group (2..8 measured equal at 20000^2; 16: 5 % slower, 64: 15 %)
-constexpr uint32_t kMaxGroups = 64;                // -> 65536 tiles
+constexpr uint32_t kMaxGroups = 256;               // -> 262144 tiles (all planes of a fused render together)
 constexpr uint32_t kRegionEntries = 262144;        // level-B region: 32 chunks
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// stream word -> tile, in-tile offset (BinLayout: e_* describe the word), and the channel filter
+// stream word -> tile (of the stack of planes), in-tile offset (BinLayout: e_* describe the word)
 __device__ __forceinline__ uint32_t tile_of(uint32_t e, const BinLayout &b) {
-  return (((e >> b.e_row_shift) & b.e_row_mask) >> kTileShift) * b.tiles_x + ((e & b.e_col_mask) >> kTileShift);
+  const uint32_t plane = (e >> b.e_chan_shift) & b.e_chan_mask;
+  const uint32_t tile_row = plane * b.tiles_y + (((e >> b.e_row_shift) & b.e_row_mask) >> kTileShift);
+  return tile_row * b.tiles_x + ((e & b.e_col_mask) >> kTileShift);
 }
 __device__ __forceinline__ uint32_t offset_of(uint32_t e, const BinLayout &b) {
   // a canvas narrower (lower) than a tile has a column (row) field of fewer bits than a tile coordinate
   return (((e >> b.e_row_shift) & b.e_row_mask & (kTileSize - 1u)) << kTileShift) |
          (e & b.e_col_mask & (kTileSize - 1u));
-}
-__device__ __forceinline__ bool taken(uint32_t e, const BinLayout &b) {
-  return b.channel < 0 || (((e >> b.e_chan_shift) >> b.channel) & 1u) != 0u;
 }
 __device__ __forceinline__ void lds_inc(uint32_t *p) {
   __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
@@ -162,19 +161,19 @@ __global__ void __launch_bounds__(kScatterThreads) bin_count_kernel(BinLayout b)
   // entries up to a 16-byte boundary, then four per load, then the tail (level-B regions start anywhere)
   uint32_t head = (4u - (uint32_t) ((reinterpret_cast<uintptr_t>(src) >> 2) & 3u)) & 3u;
   if (head > n) head = n;
-  if (threadIdx.x < head && taken(src[threadIdx.x], b)) lds_inc(&lds[P::key(b, src[threadIdx.x], k0, threadIdx.x)]);
+  if (threadIdx.x < head) lds_inc(&lds[P::key(b, src[threadIdx.x], k0, threadIdx.x)]);
   const uint32_t n4 = (n - head) >> 2;
   const uint4 *src4 = reinterpret_cast<const uint4 *>(src + head);
   for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
     const uint4 v = src4[i];
     const uint32_t j = head + (i << 2);
-    if (taken(v.x, b)) lds_inc(&lds[P::key(b, v.x, k0, j)]);
-    if (taken(v.y, b)) lds_inc(&lds[P::key(b, v.y, k0, j + 1u)]);
-    if (taken(v.z, b)) lds_inc(&lds[P::key(b, v.z, k0, j + 2u)]);
-    if (taken(v.w, b)) lds_inc(&lds[P::key(b, v.w, k0, j + 3u)]);
+    lds_inc(&lds[P::key(b, v.x, k0, j)]);
+    lds_inc(&lds[P::key(b, v.y, k0, j + 1u)]);
+    lds_inc(&lds[P::key(b, v.z, k0, j + 2u)]);
+    lds_inc(&lds[P::key(b, v.w, k0, j + 3u)]);
   }
   for (uint32_t i = head + (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
-    if (taken(src[i], b)) lds_inc(&lds[P::key(b, src[i], k0, i)]);
+    lds_inc(&lds[P::key(b, src[i], k0, i)]);
   }
   __syncthreads();
   // key-major: the scan over regions reads each key's row contiguously
@@ -259,9 +258,10 @@ __global__ void __launch_bounds__(1024) bin_scan_keys_kernel(BinLayout b) {
 }
 
 // Level-B region table from the group extents of `grouped` (a_base, scanned): group g's entries are
-// cut into regions of kRegionEntries.  One workgroup of 64 threads, one thread per group.
-__global__ void __launch_bounds__(64) bin_group_regions_kernel(BinLayout b) {
+// cut into regions of kRegionEntries.  One workgroup, one thread per group.
+__global__ void __launch_bounds__(kMaxGroups) bin_group_regions_kernel(BinLayout b) {
   __shared__ uint32_t first[kMaxGroups + 1];
+  __shared__ uint32_t wave_totals[kMaxGroups / 64];
   const uint32_t g = threadIdx.x;
   unsigned long long begin = 0, end = 0;
   uint32_t mine = 0;
@@ -271,17 +271,10 @@ __global__ void __launch_bounds__(64) bin_group_regions_kernel(BinLayout b) {
     mine = (uint32_t) ((end - begin + kRegionEntries - 1u) / kRegionEntries);
     b.group_regions[g] = mine;
   }
-  // inclusive prefix over the groups (64 lanes = one wave)
-  uint32_t inc = mine;
-#pragma unroll
-  for (uint32_t d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(inc, d, 64);
-    if (g >= d) inc += up;
-  }
-  first[g + 1] = inc;
-  if (g == 0) first[0] = 0;
+  uint32_t total = 0;
+  first[g] = block_exclusive_scan(mine, wave_totals, &total);
   __syncthreads();
-  if (g == 0) *b.n_regions = first[b.n_groups];
+  if (g == 0) *b.n_regions = total;
   if (g < b.n_groups) {
     for (uint32_t k = 0; k < mine; ++k) {
       const uint32_t r = first[g] + k;
@@ -338,8 +331,8 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
     for (uint32_t k = 0; k < kPerThread; ++k) {
       const uint32_t i = k * kScatterThreads + threadIdx.x;
       rank[k] = 0u;
-      key[k] = ~0u;  // not part of this flush (beyond the chunk, or another channel's word)
-      if (i < m && taken(e[k], b)) {
+      key[k] = ~0u;  // beyond the chunk
+      if (i < m) {
         key[k] = P::key(b, e[k], k0, base + i);
         rank[k] = __hip_atomic_fetch_add(&cnt[key[k]], 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
@@ -435,8 +428,11 @@ __global__ void __launch_bounds__(kAccThreads) bin_accumulate_kernel(BinLayout b
     lds_inc(&tile[src[i]]);
   }
   __syncthreads();
-  const uint32_t row0 = (t / b.tiles_x) << kTileShift;
-  const uint32_t col0 = (t % b.tiles_x) << kTileShift;
+  const uint32_t plane_tiles = b.tiles_x * b.tiles_y;
+  const uint32_t plane = t / plane_tiles, tt = t - plane * plane_tiles;
+  const uint32_t row0 = (tt / b.tiles_x) << kTileShift;
+  const uint32_t col0 = (tt % b.tiles_x) << kTileShift;
+  hist += (unsigned long long) plane * b.plane_pixels;
   for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) {
     const uint32_t v = tile[p];
     if (v != 0u) {
@@ -454,18 +450,19 @@ __global__ void __launch_bounds__(kAccThreads) bin_accumulate_kernel(BinLayout b
 
 struct Shape {
   bool ok;
-  uint32_t tiles_x, n_tiles, two_level, n_groups;
+  uint32_t tiles_x, n_tiles, two_level, n_groups, tiles_y;  // n_tiles: of all planes together
 };
 
-Shape shape_of(int w, int h) {
-  Shape s = {false, 0, 0, 0, 0};
-  if (w <= 0 || h <= 0 || w > 65536 || h > 65536) return s;
+Shape shape_of(int w, int h, uint32_t planes) {
+  Shape s = {false, 0, 0, 0, 0, 0};
+  if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || planes < 1u) return s;
   const uint32_t tiles_x = ((uint32_t) w + kTileSize - 1u) >> kTileShift;
   const uint32_t tiles_y = ((uint32_t) h + kTileSize - 1u) >> kTileShift;
-  const unsigned long long n = (unsigned long long) tiles_x * tiles_y;
+  const unsigned long long n = (unsigned long long) tiles_x * tiles_y * planes;
   if (n > (unsigned long long) kMaxKeys) return s;
   s.ok = true;
   s.tiles_x = tiles_x;
+  s.tiles_y = tiles_y;
   s.n_tiles = (uint32_t) n;
   s.two_level = n > kMaxTiles ? 1u : 0u;
   if (const char *e = getenv("CUDABROT_AMD_TWO_LEVEL")) {  // test knob: two levels on a small canvas
@@ -513,8 +510,8 @@ T *carve(uintptr_t &p, size_t bytes) {
 
 }  // namespace
 
-size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave) {
-  const Shape s = shape_of(w, h);
+size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wave, int n_planes) {
+  const Shape s = shape_of(w, h, (uint32_t) (n_planes > 0 ? n_planes : 1));
   if (!s.ok || n_waves == 0) return 0;
   if (entries_per_wave < 2.0 * kMinRegionEntries) entries_per_wave = 2.0 * kMinRegionEntries;
   const unsigned long long entries = (unsigned long long) (entries_per_wave * n_waves);
@@ -524,20 +521,25 @@ size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wa
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves, int n_channels) {
   BinLayout b;
   memset(&b, 0, sizeof(b));
-  b.channel = -1;
   b.e_row_shift = 16;
   b.e_col_mask = 0xffffu;
   b.e_row_mask = 0xffffu;
   b.e_chan_shift = 0;
-  if (n_channels > 0) {  // [channel set | row | col], fields as narrow as the canvas allows
-    uint32_t cb_ = 0, rb = 0;
+  b.e_chan_mask = 0;
+  b.n_planes = n_channels > 0 ? (uint32_t) n_channels : 1u;
+  b.plane_pixels = (unsigned long long) (w > 0 ? w : 0) * (unsigned long long) (h > 0 ? h : 0);
+  if (n_channels > 0) {  // [channel | row | col], fields as narrow as the canvas allows
+    uint32_t cb_ = 0, rb = 0, nb = 0;
     while ((1u << cb_) < (uint32_t) (w > 1 ? w : 1)) ++cb_;
     while ((1u << rb) < (uint32_t) (h > 1 ? h : 1)) ++rb;
-    if (w <= 0 || h <= 0 || cb_ + rb + (uint32_t) n_channels > 32u) return b;  // no room: direct atomics
+    while ((1u << nb) < (uint32_t) n_channels) ++nb;
+    // the draw kernel tags a word with channel << e_chan_shift whether or not the stream is used
+    b.e_chan_shift = (cb_ + rb + nb <= 32u && cb_ + rb < 32u) ? cb_ + rb : 0u;
+    b.e_chan_mask = (1u << nb) - 1u;
+    if (w <= 0 || h <= 0 || cb_ + rb + nb > 32u) return b;  // no room: direct atomics
     b.e_row_shift = cb_;
     b.e_col_mask = (1u << cb_) - 1u;
     b.e_row_mask = (1u << rb) - 1u;
-    b.e_chan_shift = cb_ + rb;
   }
   b.slice_entries = kSliceEntriesDefault;
   if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob
@@ -545,10 +547,11 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
     if (v >= 4096 && v <= (1l << 30)) b.slice_entries = (uint32_t) v;
   }
   b.n_waves = n_waves;
-  const Shape s = shape_of(w, h);
+  const Shape s = shape_of(w, h, b.n_planes);
   if (!workspace || n_waves == 0 || !s.ok) return b;
   b.n_tiles = s.n_tiles;
   b.tiles_x = s.tiles_x;
+  b.tiles_y = s.tiles_y;
   b.two_level = s.two_level;
   b.n_groups = s.n_groups;
   // align the carve to 256 bytes
@@ -607,7 +610,7 @@ hipError_t launch_pass(const BinLayout &b, uint32_t n_keys_lds, uint32_t total_k
   hipLaunchKernelGGL((bin_count_kernel<kLevelA>), dim3(regions), dim3(kScatterThreads), count_lds, stream, b);
   hipLaunchKernelGGL((bin_scan_rows_kernel<kLevelA>), dim3(total_keys), dim3(256), 0, stream, b);
   hipLaunchKernelGGL((bin_scan_keys_kernel<kLevelA>), dim3(1), dim3(1024), 0, stream, b);
-  if (kLevelA) hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(64), 0, stream, b);
+  if (kLevelA) hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(kMaxGroups), 0, stream, b);
   const size_t scatter_lds = ((size_t) 3 * n_keys_lds + 8 + 2 * kChunkEntries) * sizeof(uint32_t);
   if (scatter_lds > 64 * 1024) {  // 76 KiB at 1024 keys, 112 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_scatter_kernel<kLevelA>),

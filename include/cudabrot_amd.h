@@ -157,16 +157,16 @@ int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32
  * The reference's colour recipe (generate_hires_color_image.sh:27-59) runs the program once per
  * channel with different -m / -c.  All runs draw the same sample stream, so one pass can serve them:
  * every sample is iterated once up to the largest max, and its orbit is replayed once into every
- * channel j whose window windows[j].min <= k < windows[j].max holds the escape index k.  d_hist is
+ * channel j whose window windows[j].min <= k < windows[j].max holds the escape index k; the planes are
+ * then sorted and accumulated together, as one taller canvas.  d_hist is
  * n_channels planes of w*h counters, plane j = what cb_draw_buddhabrot would add with windows[j].
  * The wave-scheduled kernel only (variant flags as above); cb_flush_scatter_channels after each
  * launch that was given a workspace (sized by cb_scatter_workspace_bytes).
  * Counters of a fused launch: samples, rejected, never_escaped (against the largest max) and
  * iterate_steps as for one run with the largest max; too_fast = orbits that escaped but whose index
- * lies in no window; recorded = orbits in at least one window; replay_steps counts both replays (the
- * first, unrecorded one finds the escape index); increments = in-canvas points recorded, each of which
- * adds one to EVERY plane of its orbit's channel set (so the planes' sum is >= increments, with
- * equality when the windows are disjoint). */
+ * lies in no window; recorded = orbits in at least one window; replay_steps counts every replay (a first,
+ * unrecorded one finds the escape index, then one per channel the orbit belongs to); increments = the
+ * histogram increments of all planes together. */
 int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                                 const cb_iteration_control *windows, int n_channels, void *d_states,
                                 uint32_t n_threads, uint32_t samples_per_thread, cb_counters *d_counters,

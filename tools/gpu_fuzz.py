@@ -221,10 +221,7 @@ def main():
                 wc = dict(gc)                      # per-window counters do not add up to the fused run's ...
                 wc["samples"] = singles[0][1]["samples"]
                 wc["rejected"] = singles[0][1]["rejected"]
-                # ... and `increments` counts recorded points, not the planes they went to (cudabrot_amd.h)
-                each = [c["increments"] for _, c in singles]
-                if not (max(each) <= gc["increments"] <= sum(each)) or int(got.sum()) != sum(each):
-                    wc["increments"] = -1
+                wc["increments"] = sum(c["increments"] for _, c in singles)   # ... except these
             else:
                 want, wc = render(t, cb.CB_KERNEL_SIMPLE)
                 got, gc = render(t, cb.CB_KERNEL_DEFAULT)
