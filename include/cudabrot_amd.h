@@ -113,9 +113,10 @@ size_t cb_rng_state_bytes(uint32_t n_threads);
 int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
                       void *stream);
 
-/* Suggested size of the scatter workspace of cb_draw_buddhabrot for launches of this shape (0 if the
- * canvas cannot use one: more than 4096 tiles of 128x128 pixels, or a side above 65536).  Any size
- * works: increments that do not fit are added with direct atomics, the result is the same. */
+/* Suggested size of the scatter workspace of cb_draw_buddhabrot (and cb_draw_buddhabrot_channels) for
+ * launches of this shape (0 if the canvas cannot use one: more than 262144 tiles of 128x128 pixels, or a
+ * side above 65536).  Any size works: increments that do not fit are added with direct atomics, the
+ * result is the same. */
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
                                   uint32_t samples_per_thread);
 
