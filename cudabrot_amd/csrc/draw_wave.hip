@@ -1124,9 +1124,12 @@ draw_wave_kernel(DrawArgs a) {
 #endif
             hit = p_real && pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);  // cudabrot.cu:308-311 (halving is exact)
             if (hit) {                                                 // cudabrot.cu:312
-              // fused channels: the plane of the channel this pass records into
-              add_to_pixel(a.hist + (unsigned long long) (p_tag >> a.bin.e_chan_shift) * a.plane_pixels, cv, row,
-                           col, 1ull);
+              if (!multi) {
+                add_to_pixel(a.hist, cv, row, col, 1ull);
+              } else {  // the plane of the channel this pass records into
+                add_to_pixel(a.hist + (unsigned long long) (p_tag >> a.bin.e_chan_shift) * a.plane_pixels, cv, row,
+                             col, 1ull);
+              }
             }
             p_steps++;
             done = m4 > 16.0;                                          // cudabrot.cu:363
