@@ -113,3 +113,44 @@ def test_renderer_with_channels_pipelines_launches_and_tone_maps_each_plane(cb, 
         assert np.array_equal(planes[j], ref)
     gray, mx_ref, _ = oracle.set_grayscale_pixels(planes[1], 2.2)
     assert mx == mx_ref and np.array_equal(body.astype(np.uint16), gray)
+
+
+def test_four_planes_of_the_recipe_canvas_are_more_than_65536_tiles(cb):
+    """20000 x 15000 x 4 planes = 74 104 tiles of the stacked canvas (two sort levels, 73 groups): each plane
+    must equal a single-window run of the same kernel with direct atomics (that path is pinned to the oracle
+    by the tests above; the oracle itself would need minutes for this size).  Compared on the device."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    w, h, t, spt = 20000, 15000, 65536, 100
+    box = (-2.0, 2.0, -1.5, 1.5)
+    windows = [(3000, 1000), (1000, 200), (200, 20), (3000, 20)]     # the last one overlaps the others
+    dims = cb.FractalDimensions.make(w, h, *box)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def states():
+        s = torch.empty(cb.rng_state_bytes(t), dtype=torch.uint8, device=dev)
+        cb.initialize_rng(1337, 0, t, s.data_ptr(), stream)
+        return s
+
+    planes = torch.zeros(len(windows) * w * h, dtype=torch.int64, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    ws_bytes = cb.scatter_workspace_bytes(dims, t, spt)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    st = states()
+    cb.draw_buddhabrot_channels(dims, planes.data_ptr(), windows, st.data_ptr(), t, spt, counters.data_ptr(),
+                                cb.CB_KERNEL_DEFAULT, stream, ws.data_ptr(), ws_bytes)
+    cb.flush_scatter_channels(dims, planes.data_ptr(), len(windows), t, ws.data_ptr(), ws_bytes, stream)
+    torch.cuda.synchronize()
+    c = counters.cpu().numpy().view(np.uint64)
+    assert int(c[9]) == 0
+    total = 0
+    for j, (m, cmin) in enumerate(windows):
+        one = torch.zeros(w * h, dtype=torch.int64, device=dev)
+        st = states()
+        cb.draw_buddhabrot(dims, one.data_ptr(), cb.IterationControl(m, cmin), st.data_ptr(), t, spt)
+        torch.cuda.synchronize()
+        assert torch.equal(planes[j * w * h:(j + 1) * w * h], one), "plane %d" % j
+        total += int(one.sum().item())
+        del one
+    assert total == int(c[7]) > 0       # `increments` counts all planes
