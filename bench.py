@@ -127,7 +127,7 @@ def baseline_metric():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)   # 0.6 s of launches: the one drain launch at the end (15 ms) is 2 % of it
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")

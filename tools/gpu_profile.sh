@@ -17,7 +17,7 @@ run() {  # run <seconds> <logfile> <cmd...>
   return 0
 }
 BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate"
-run 400 "$OUT/bench_full.json" python3 bench.py --steps 10 --warmup 2
+run 400 "$OUT/bench_full.json" python3 bench.py
 run 300 "$OUT/stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS
 run 300 "$OUT/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS
 run 300 "$OUT/pmc_write.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS
