@@ -79,11 +79,32 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   a.pow2_imag = exact_reciprocal(dims->delta_imag, &a.inv_delta_imag) ? 1 : 0;
   a.rcp_delta_real = 1.0 / dims->delta_real;  // only ever an estimate: any value (inf, nan) is safe
   a.rcp_delta_imag = 1.0 / dims->delta_imag;
+  a.replay_min2_real = dims->min_real + dims->min_real;
+  a.replay_min2_imag = dims->min_imag + dims->min_imag;
+  if (a.pow2_real && a.pow2_imag) {
+    a.replay_scale_real = 0.5 * a.inv_delta_real;
+    a.replay_scale_imag = 0.5 * a.inv_delta_imag;
+    a.replay_offset_real = -(dims->min_real * a.inv_delta_real);
+    a.replay_offset_imag = -(dims->min_imag * a.inv_delta_imag);
+  } else {
+    a.replay_scale_real = dims->delta_real;
+    a.replay_scale_imag = dims->delta_imag;
+    a.replay_offset_real = dims->min_real;
+    a.replay_offset_imag = dims->min_imag;
+  }
   a.w = dims->w;
   a.h = dims->h;
   a.max_iter = it->max_escape_iterations;
   a.min_iter = it->min_escape_iterations;
   cb::plan_stages(a.max_iter, a.min_iter, &a.head_steps, &a.mid_steps);
+  {
+    const int long_steps = a.max_iter - (a.head_steps + a.mid_steps);
+    a.long_steps = long_steps > 0 ? (uint32_t) long_steps : 0u;
+    a.tail_steps = a.long_steps % (uint32_t) cb::kChunk;
+    a.tail_value = a.tail_steps ? a.tail_steps : ~0u;
+    a.accept_rem = a.max_iter - a.min_iter;
+    a.fast_mid = (a.min_iter >= a.head_steps + a.mid_steps && long_steps > 0) ? 1 : 0;
+  }
   a.n_threads = n_threads;
   a.samples_per_thread = samples_per_thread;
   a.hist = reinterpret_cast<unsigned long long *>(d_hist);

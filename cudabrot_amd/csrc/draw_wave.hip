@@ -803,6 +803,15 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 // Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for
 // 64 * n_steps more entries.  On return `act` holds the lanes still replaying, `fill` the new fill,
 // lane_steps / hits the executed lane-steps and the entries appended.  p holds DOUBLED coordinates.
+// The kernel's arguments, read afresh: a scalar load from the argument segment at the point of use
+// instead of a value held in (and spilled from) scalar registers since the kernel began.
+typedef const DrawArgs __attribute__((address_space(4))) *KernelArgs;
+__device__ __forceinline__ KernelArgs fresh_args() {
+  KernelArgs p = (KernelArgs) __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 template <bool kPow2>
 __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                              int &p_steps, const Canvas &cv, uint32_t *region,
@@ -814,9 +823,10 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   double a, fx, fy, d0, d1, d2, d3;
   uint32_t col, row, pidx, e;
   // All "s" operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
-  const double minx2 = uniform_f64(cv.min_real + cv.min_real), miny2 = uniform_f64(cv.min_imag + cv.min_imag);
-  const uint32_t w = __builtin_amdgcn_readfirstlane((uint32_t) cv.w);
-  const uint32_t h = __builtin_amdgcn_readfirstlane((uint32_t) cv.h);
+  (void) cv;
+  const KernelArgs ka = fresh_args();
+  const double minx2 = ka->replay_min2_real, miny2 = ka->replay_min2_imag;
+  const uint32_t w = (uint32_t) ka->w, h = (uint32_t) ka->h;
   region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
@@ -827,8 +837,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   if (kPow2) {
     // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
     // a VALU instruction reads one scalar operand
-    const double sx = uniform_f64(0.5 * cv.inv_delta_real), sy = uniform_f64(0.5 * cv.inv_delta_imag);
-    const double ox = -(cv.min_real * cv.inv_delta_real), oy = -(cv.min_imag * cv.inv_delta_imag);
+    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
     asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
@@ -841,9 +851,9 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
   } else {
-    const double sx = uniform_f64(cv.delta_real), sy = uniform_f64(cv.delta_imag);
-    const double ox = uniform_f64(cv.min_real), oy = uniform_f64(cv.min_imag);
-    const double rx = uniform_f64(cv.rcp_delta_real), ry = uniform_f64(cv.rcp_delta_imag);
+    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+    const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
     asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
@@ -925,20 +935,11 @@ draw_wave_kernel(DrawArgs a) {
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q1_cr[0])));
   const uint32_t q2_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q2_cr[0])));
-  // MID as one asm block (mid_pass) under the usual split: HEAD did four iterations, every escape inside
-  // MID is too fast (the stage ends at or before min_iter) and survivors have iterations left
-  const bool fast_mid = kFastHead && (min_iter >= long_start) && (long_steps > 0);
   // LONG lane state: two orbits per lane (see CB_STEP2)
   Orbit lo[kOrbitsPerLane] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
   int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
   uint32_t skip_lo = 0, skip_hi = 0;  // per lane, 64 bits: iterations the periodicity check made unnecessary
-  // (wave-uniform values that feed "s" operands of the asm blocks go through readfirstlane once, here)
-  const uint32_t tail_value =  // l_rem of a lane left with the tail chunk
-      __builtin_amdgcn_readfirstlane(tail_steps ? (uint32_t) tail_steps : ~0u);
-  const int accept_rem = (int) __builtin_amdgcn_readfirstlane((uint32_t) (max_iter - min_iter));
-  const uint32_t check_flag = __builtin_amdgcn_readfirstlane((uint32_t) a.check_periodic);
-  const uint32_t long_steps_u = __builtin_amdgcn_readfirstlane((uint32_t) long_steps);
   // REPLAY lane state
   Orbit po = {0, 0, 0, 0};
   bool p_act = false;
@@ -1230,11 +1231,14 @@ draw_wave_kernel(DrawArgs a) {
     if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       const int n = q0_count < 64 ? q0_count : 64;
-      if (fast_mid) {  // the usual split: MID ends at or before min_iter and LONG follows
+      // MID as one asm block (mid_pass) under the usual split: HEAD did four iterations, every escape inside
+      // MID is too fast (the stage ends at or before min_iter) and survivors have iterations left
+      const KernelArgs ma = fresh_args();
+      if (kFastHead && ma->fast_mid) {
         const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
         unsigned long long alive;
         uint32_t steps;
-        mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) mid_steps,
+        mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
                  (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
         q0_head = (q0_head + n) & (kQ0Cap - 1);
         q0_count -= n;
@@ -1297,6 +1301,11 @@ draw_wave_kernel(DrawArgs a) {
 
     // ---------------------------------------------------------------- LONG
     const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+    // the stage's constants: scalar loads from the argument segment on entry (fresh_args)
+    const KernelArgs la = fresh_args();
+    const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
+    const uint32_t check_flag = (uint32_t) la->check_periodic;
+    const int accept_rem = la->accept_rem;
     for (;;) {
       // Even progress for the waves of a SIMD.  VALU issue goes by priority, then by wave age, so
       // with equal priorities the oldest wave races ahead and the youngest is left to finish alone,

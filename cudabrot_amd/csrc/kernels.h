@@ -85,8 +85,22 @@ struct DrawArgs {
   // canvas (cudabrot.cu:46-58) + exact-reciprocal fast path
   double min_real, min_imag, delta_real, delta_imag, inv_delta_real, inv_delta_imag;
   int w, h, pow2_real, pow2_imag;
-  // RN(1 / delta) for any delta: the replay burst's quotient estimate (draw_wave.hip, CB_REPLAY_BIN_EST)
+  // RN(1 / delta) for any delta: the replay burst's quotient estimate (draw_wave.hip, CB_REPLAY_BIN_DIV)
   double rcp_delta_real, rcp_delta_imag;
+  // The replay burst's wave-constant operands, made on the host (capi.hip, make_args) so that the kernel reads
+  // them from its argument segment with scalar loads where they are used: neither vector instructions to
+  // derive them nor scalar registers to hold them across the other stages.
+  //   2 min (the tests R >= 2 min_re on doubled coordinates);
+  //   dyadic pixels: scale = 0.5 / delta, offset = -(min / delta)  (pixel = fma(R, scale, offset));
+  //   else:          scale = delta, offset = min                  (pixel = (R / 2 - offset) / scale)
+  double replay_min2_real, replay_min2_imag;
+  double replay_scale_real, replay_scale_imag, replay_offset_real, replay_offset_imag;
+  // Likewise the LONG stage's constants (from max_iter, min_iter and the stage split): iterations left to
+  // the stage, the length of an orbit's last, shorter chunk and the l_rem that marks it (~0: none), and the
+  // largest l_rem at which an escape is accepted (max_iter - min_iter)
+  uint32_t long_steps, tail_steps, tail_value;
+  int accept_rem;
+  int fast_mid;  // the usual split: MID ends at or before min_iter and the LONG stage follows
   // iteration control (cudabrot.cu:62-67)
   int max_iter, min_iter;
   // stage split of draw_wave_kernel (plan_stages): HEAD runs iterations [0, head_steps), MID the
