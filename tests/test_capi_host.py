@@ -138,3 +138,50 @@ def test_header_is_plain_c_and_the_library_links_from_c(cb, repo_root, tmp_path)
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.split() == ["1", "136", "1536", "32767"]
+
+
+def test_every_entry_point_rejects_null_or_nonsense_arguments(cb):
+    """The C ABI returns an error code (never crashes, never touches the device) for null handles and
+    pointers, empty canvases, zero thread counts and channel counts out of range (cudabrot_amd.h: every
+    function returns 0 or a hipError_t value)."""
+    import ctypes as C
+
+    lib = cb.capi.lib
+    d = cb.FractalDimensions.make(16, 16)
+    empty = cb.FractalDimensions(0, 16, -2.0, -2.0, 2.0, 2.0, 0.25, 0.25)
+    it = cb.IterationControl(100, 20)
+    null = C.c_void_p(0)
+    windows = (cb.IterationControl * 5)(*[cb.IterationControl(100, 20)] * 5)
+    bad = [
+        lib.cb_initialize_rng(1337, 0, 64, null, null),
+        lib.cb_draw_buddhabrot(C.byref(d), null, C.byref(it), null, 64, 50, null, 0, null, 0, null, null),
+        lib.cb_draw_buddhabrot(C.byref(empty), 8, C.byref(it), 8, 64, 50, null, 0, null, 0, null, null),
+        lib.cb_draw_buddhabrot(C.byref(d), 8, C.byref(it), 8, 64, 50, null, 77, null, 0, null, null),  # no such kernel variant
+        lib.cb_flush_scatter(C.byref(d), null, 64, null, 0, null),
+        lib.cb_flush_scatter(C.byref(empty), 8, 64, null, 0, null),
+        lib.cb_draw_buddhabrot_channels(C.byref(d), 8, windows, 0, 8, 64, 50, null, 0, null, 0, null, null),
+        lib.cb_draw_buddhabrot_channels(C.byref(d), 8, windows, 5, 8, 64, 50, null, 0, null, 0, null, null),
+        lib.cb_flush_scatter_channels(C.byref(d), 8, 0, 64, null, 0, null),
+        lib.cb_flush_scatter_channels(C.byref(d), 8, 5, 64, null, 0, null),
+        lib.cb_renderer_render_passes(null, 1, 0),
+        lib.cb_renderer_prepare(null, 0),
+        lib.cb_renderer_finish(null),
+        lib.cb_renderer_read_histogram(null, null),
+        lib.cb_renderer_write_histogram(null, null),
+        lib.cb_renderer_read_counters(null, None),
+        lib.cb_renderer_read_rng_states(null, null),
+        lib.cb_renderer_write_rng_states(null, null),
+        lib.cb_renderer_grayscale_image(null, 1.0, 0, null, None, None),
+        lib.cb_renderer_grayscale_plane(null, 0, 1.0, 0, null, None, None),
+        lib.cb_renderers_reduce(None, 2),
+        lib.cb_tone_map_device(null, 16, 16, 1.0, 0, null, None, None, null),
+    ]
+    assert all(rc != 0 for rc in bad), bad
+    out = C.c_void_p()
+    assert lib.cb_renderer_create(C.byref(out), 0, C.byref(empty), C.byref(it), 1337, 0, 64) != 0 and not out.value
+    assert lib.cb_renderer_create_channels(C.byref(out), 0, C.byref(d), windows, 5, 1337, 0, 64) != 0 and not out.value
+    assert lib.cb_scatter_workspace_bytes(C.byref(empty), 64, 50) == 0
+    assert lib.cb_scatter_workspace_bytes(C.byref(d), 0, 50) == 0
+    assert lib.cb_renderer_device_histogram(null) in (None, 0)
+    lib.cb_renderer_destroy(null)     # a no-op
+    assert cb.capi._error_string(bad[0])   # every code has a name
