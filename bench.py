@@ -393,25 +393,28 @@ def main():
         if world == 1 and not args.no_full_iterate:
             # the iterate loop against its roofline: the same launch with the periodicity early-out off,
             # i.e. every sample iterated to max_iter as the reference does (same histogram)
-            # (driven like the product: carry buffer, so that the waves pace themselves by the progress board; two
-            # launches and the drain launch that completes them, every executed iteration over all three)
+            # (driven like the product: carry buffer, so that the waves pace themselves by the progress board; six
+            # launches and the drain launch that completes them, every executed iteration over all seven)
             counters.zero_()
             fcarry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
             torch.cuda.synchronize()
-            fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+            FULL_LAUNCHES = 6
+            fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                   for _ in range(FULL_LAUNCHES + 1)]
             for n, (a, b) in enumerate(fev):
                 a.record()
                 cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads,
-                                   samples_per_thread if n < 2 else 0, counters.data_ptr(), cb.CB_KERNEL_FULL_ITERATE,
+                                   samples_per_thread if n < FULL_LAUNCHES else 0, counters.data_ptr(),
+                                   cb.CB_KERNEL_FULL_ITERATE,
                                    stream, workspaces[0].data_ptr() if ws_bytes else 0, ws_bytes, fcarry.data_ptr())
                 b.record()
                 if ws_bytes:
                     cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
             torch.cuda.synchronize()
             f_each = [a.elapsed_time(b) for a, b in fev]
-            fms = sum(f_each) / 2.0          # per launch of samples: the drain launch's time is shared by the two
+            fms = sum(f_each) / FULL_LAUNCHES    # per launch of samples: the drain launch's time is shared by them
             fc = dict(zip(cnt.keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
-            fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / 2.0
+            fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / FULL_LAUNCHES
             ftf = fiters * FLOPS_PER_ITERATION / (fms * 1e-3) / 1e12
             line["roofline_full_iterate"] = {
                 "bound": "valu_fp64",
@@ -423,7 +426,7 @@ def main():
                 "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
                 "issue_frac": round(ftf / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(fms, 4),
-                "launch_ms": [round(x, 3) for x in f_each],   # two launches of samples, then the drain launch
+                "launch_ms": [round(x, 3) for x in f_each],   # the launches of samples, then the drain launch
                 "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
             }
         if world == 1 and not args.no_reference:
