@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--no-full-iterate", action="store_true",
-                    help="skip the extra two launches that measure the iterate loop with the early-out off")
+                    help="skip the extra launches that measure the iterate loop with the early-out off")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
     args = ap.parse_args()
