@@ -370,7 +370,8 @@ def main():
                         "previous launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, "
                         "after the clock); the kernel executes an iteration as 6 fp64 instructions + 1 compare "
                         "(doubled-coordinate form of the 10-flop step), so the ceiling of `frac` is 10/14 = 0.714; "
-                        "issue_frac = fp64 issue-slot utilisation (7 per iteration)",
+                        "issue_frac = fp64 issue-slot utilisation (7 per iteration); peak is the 2.4 GHz spec figure, "
+                        "the shader clock under this load is ~2.08 GHz (DESIGN.md 4.4)",
             },
             "roofline_scatter": {
                 "bound": "hbm",
