@@ -38,6 +38,36 @@ __global__ void __launch_bounds__(256) stream_read(const uint4 *src, size_t n_ve
   if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The same with a register allocation of at least kVgprs (a clobbered top register) and, with kScratch, a
+// private array indexed at run time (scratch memory): which guests find room beside the draw kernel?
+template <int kVgprs, bool kScratch>
+__global__ void __launch_bounds__(256) stream_read_shaped(const uint4 *src, size_t n_vec, unsigned *sink) {
+  extern __shared__ unsigned lds[];
+  lds[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  if (kVgprs == 32) asm volatile("" ::: "v31");
+  if (kVgprs == 48) asm volatile("" ::: "v47");
+  if (kVgprs == 56) asm volatile("" ::: "v55");
+  if (kVgprs == 64) asm volatile("" ::: "v63");
+  if (kVgprs == 72) asm volatile("" ::: "v71");
+  unsigned priv[16];
+  if (kScratch) {
+    for (int k = 0; k < 16; ++k) priv[k] = lds[(threadIdx.x + k) & 255];
+  }
+  const size_t stride = (size_t) gridDim.x * blockDim.x;
+  size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned acc = lds[(threadIdx.x + 1) & 255];
+  for (; i + 3 * stride < n_vec; i += 4 * stride) {
+    const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc += a.x ^ b.y ^ c.z ^ d.w;
+    if (kScratch) {
+      priv[a.x & 15u] += acc;
+      acc ^= priv[b.y & 15u];
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 int main(int argc, char **argv) {
   const size_t read_bytes = (size_t) 6 << 30;
   cb_fractal_dimensions dims = {};
@@ -112,6 +142,39 @@ int main(int argc, char **argv) {
       printf("lds %6d B x %d WG/CU: read alone %.3f ms (%.2f TB/s) | together: draw %.3f ms, read %.3f ms (%.2f TB/s), "
              "span from draw start to read end %.3f ms\n",
              lds, wpc, alone, read_bytes / alone * 1e-9, d, s, read_bytes / s * 1e-9, span);
+      fflush(stdout);
+    }
+  }
+  // shaped guests: registers / scratch at the LDS sizes a small sort kernel would need, one workgroup per CU
+  struct Shape { const char *name; const void *fn; };
+  const Shape shapes[] = {
+      {"32 VGPR", (const void *) stream_read_shaped<32, false>}, {"48 VGPR", (const void *) stream_read_shaped<48, false>},
+      {"56 VGPR", (const void *) stream_read_shaped<56, false>}, {"64 VGPR", (const void *) stream_read_shaped<64, false>},
+      {"72 VGPR", (const void *) stream_read_shaped<72, false>}, {"32 VGPR + scratch", (const void *) stream_read_shaped<32, true>},
+  };
+  for (const Shape &sh : shapes) {
+    for (int lds : {20480, 28672}) {
+      CHECK(hipFuncSetAttribute(sh.fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      void *args[] = {&src, (void *) nullptr, &sink};
+      size_t n_vec = read_bytes / 16;
+      args[1] = &n_vec;
+      CHECK(hipEventRecord(b0, sb));
+      CHECK(hipLaunchKernel(sh.fn, dim3(256), dim3(256), args, lds, sb));
+      CHECK(hipEventRecord(b1, sb));
+      CHECK(hipDeviceSynchronize());
+      float alone;
+      CHECK(hipEventElapsedTime(&alone, b0, b1));
+      CHECK(hipEventRecord(a0, sa)); draw(); CHECK(hipEventRecord(a1, sa));
+      CHECK(hipEventRecord(b0, sb));
+      CHECK(hipLaunchKernel(sh.fn, dim3(256), dim3(256), args, lds, sb));
+      CHECK(hipEventRecord(b1, sb));
+      CHECK(hipDeviceSynchronize());
+      float d, s2, span;
+      CHECK(hipEventElapsedTime(&d, a0, a1));
+      CHECK(hipEventElapsedTime(&s2, b0, b1));
+      CHECK(hipEventElapsedTime(&span, a0, b1));
+      printf("guest %-18s lds %5d B: alone %.3f ms | together: draw %.3f ms, guest %.3f ms, span %.3f ms  -> %s\n",
+             sh.name, lds, alone, d, s2, span, span < d + 0.5f * alone ? "RUNS BESIDE the draw kernel" : "waits for it");
       fflush(stdout);
     }
   }
