@@ -62,6 +62,8 @@ def _load():
     lib_.orc_in_order2_bulb.argtypes = [dbl, dbl]
     lib_.orc_iterate_mandelbrot.restype = i32
     lib_.orc_iterate_mandelbrot.argtypes = [dbl, dbl, i32]
+    lib_.orc_iterate_and_record.restype = u64
+    lib_.orc_iterate_and_record.argtypes = [C.POINTER(Dims), vp, dbl, dbl, C.POINTER(u64)]
     lib_.orc_draw_buddhabrot.argtypes = [C.POINTER(Dims), vp, C.POINTER(Iters), vp, u64, i32, C.POINTER(Counters)]
     lib_.orc_draw_buddhabrot_omp.restype = i32
     lib_.orc_draw_buddhabrot_omp.argtypes = [C.POINTER(Dims), vp, C.POINTER(Iters), vp, u64, i32,
@@ -134,6 +136,18 @@ def render(w, h, max_iter, min_iter, n_threads, passes, box=(-2.0, 2.0, -2.0, 2.
     finally:
         lib.orc_set_burning_ship(0)
     return hist, cnt.as_dict()
+
+
+def record_points(w, h, box, re, im):
+    """IterateAndRecord (cudabrot.cu:347-365) for each given starting point, one after another ->
+    (u64 hist [h,w], replay steps, increments).  Every point must escape (the caller checked)."""
+    d = make_dims(w, h, box[0], box[1], box[2], box[3])
+    hist = np.zeros((h, w), dtype=np.uint64)
+    incr = C.c_uint64(0)
+    steps = 0
+    for a, b in zip(re, im):
+        steps += int(lib.orc_iterate_and_record(C.byref(d), hist.ctypes.data, float(a), float(b), C.byref(incr)))
+    return hist, steps, int(incr.value)
 
 
 def fnv1a_pixels(hist):

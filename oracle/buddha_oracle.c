@@ -243,6 +243,17 @@ static inline void iterate_and_record(double start_real, double start_imag, uint
   }
 }
 
+/* cudabrot.cu:347-365 for a caller-given starting point (the caller guarantees that it escapes);
+ * returns the iterations executed and adds the in-canvas increments to *increments if not NULL. */
+uint64_t orc_iterate_and_record(const orc_dims *dims, uint64_t *hist, double start_real, double start_imag,
+                                uint64_t *increments) {
+  orc_counters c;
+  memset(&c, 0, sizeof(c));
+  iterate_and_record(start_real, start_imag, hist, dims, 0, &c);
+  if (increments) *increments += c.increments;
+  return c.replay_steps;
+}
+
 /* One "thread" of DrawBuddhabrot, cudabrot.cu:381-413 */
 static void draw_thread(const orc_dims *dims, uint64_t *hist, const orc_iters *it,
                         orc_xorwow *rng, int samples_per_thread, int atomic, orc_counters *c) {

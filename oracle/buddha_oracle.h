@@ -75,6 +75,10 @@ int orc_in_main_cardioid(double real, double imag);
 int orc_in_order2_bulb(double real, double imag);
 /* cudabrot.cu:319-340 */
 int orc_iterate_mandelbrot(double start_real, double start_imag, int max_iterations);
+/* cudabrot.cu:347-365 (IterateAndRecord, with IncrementPixelCounter :302-314) for one starting point that is
+ * known to escape; returns the iterations executed, adds the in-canvas increments to *increments. */
+uint64_t orc_iterate_and_record(const orc_dims *dims, uint64_t *hist, double start_real, double start_imag,
+                                uint64_t *increments);
 /* RENDER_BURNING_SHIP (cudabrot.cu:15-17) as a run-time switch of this library (process-wide). */
 void orc_set_burning_ship(int on);
 int orc_get_burning_ship(void);

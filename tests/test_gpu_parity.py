@@ -94,6 +94,8 @@ def test_full_histogram_vs_oracle(cb, oracle, cfg, variant_name):
         (3001, 1001),
         (2999, 1007),
         (8000, 1000),   # generate_hires_color_image.sh "medium"
+        (60000, 45000), # generate_hires_color_image.sh "fine": ~1500 LONG chunks before the first acceptable escape
+        (60007, 45011), # ... with a tail chunk and min_iter off the chunk grid
     ],
 )
 def test_iteration_window_edges(cb, oracle, max_iter, min_iter):

@@ -104,3 +104,23 @@ def test_burning_ship_goldens(oracle, g):
     assert int(hist.max()) == g["max"]
     assert int((hist > 0).sum()) == g["nonzero"]
     assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"]
+
+
+def test_full_size_fixture_small_row(oracle):
+    """tests/golden/full_size.json (BASELINE.json's C4 / C5 from the reference's own lines): its one small row,
+    the recipe's deepest window -m 60000 -c 45000 on 300 x 300, pins the oracle on the CPU as well (the
+    full-size rows are checked against the product on the GPU box, tests/test_gpu_full_size.py)."""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "full_size.json")) as f:
+        rows = {g["name"]: g for g in json.load(f)["histograms"]}
+    assert {"c4_20000_m20000", "c5_recipe_m60000_c45000", "c5_recipe_m8000_c1000", "c5_recipe_m500_c20",
+            "c5_baseline_m200", "c5_baseline_m2000", "c5_baseline_m20000"} <= set(rows)
+    g = rows["small_m60000_c45000"]
+    hist, cnt = oracle.render(g["w"], g["h"], g["max_iter"], g["min_iter"], g["threads"], g["passes"], tuple(g["box"]),
+                              omp_threads=0)
+    assert cnt["samples"] == g["samples"]
+    assert int(hist.sum()) == g["increments"] == cnt["increments"]
+    assert int(hist.max()) == g["max"] and int((hist > 0).sum()) == g["nonzero"]
+    assert "%016x" % oracle.fnv1a_pixels(hist) == g["fnv1a64"]
