@@ -29,6 +29,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# --config: C3 is BASELINE.json's metric config (and the default); C4 is its 8-GPU headline canvas; C2 the
+# shallower 4096^2 case.  (w, h, max_iter, min_iter); every canvas spans [-2,2]^2 (cudabrot.cu:533-538).
+CONFIGS = {
+    "C3": (4096, 4096, 20000, 20),
+    "C4": (20000, 20000, 20000, 20),
+    "C2": (4096, 4096, 2000, 20),
+}
 W = H = 4096
 MAX_ITER, MIN_ITER = 20000, 20
 THREADS = 512 * 512
@@ -135,7 +142,11 @@ def main():
                     help="skip the extra launches that measure the iterate loop with the early-out off")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3",
+                    help="workload: C3 (default, the config BASELINE.json's metric is quoted on), C4 (20000x20000), C2")
     args = ap.parse_args()
+    global W, H, MAX_ITER, MIN_ITER
+    W, H, MAX_ITER, MIN_ITER = CONFIGS[args.config]
 
     import numpy as np
     import torch
@@ -229,6 +240,7 @@ def main():
     step(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
     fence()
     counters.zero_()
+    hist.zero_()     # from here on every increment the histogram holds is also in `counters`
     torch.cuda.synchronize()
     ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(args.steps)]
     dev_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -274,7 +286,7 @@ def main():
                            cb.CB_KERNEL_DEFAULT, stream, workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
         cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
         torch.cuda.synchronize()
-    extra_samples = int(counters.cpu().numpy().view(np.uint64)[0]) - int(counters_timed.cpu().numpy().view(np.uint64)[0])
+    counters_all = counters.clone()  # timed region + the scatter-timing launches: everything the histogram holds
     counters.copy_(counters_timed)   # the checks and per-launch figures below are about the timed region
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -286,11 +298,15 @@ def main():
     c_local = counters.clone()
     if world > 1:
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        dist.all_reduce(counters_all, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    t_red = time.perf_counter()
     if same_device and world > 1:
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)   # gloo has no reduce() for device tensors
     else:
         reduce_histogram(hist, dst=0)
     torch.cuda.synchronize()
+    reduce_ms = (time.perf_counter() - t_red) * 1e3
     cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
     loc = dict(zip(cnt.keys(), (int(v) for v in c_local.cpu().numpy().view(np.uint64))))
 
@@ -298,10 +314,11 @@ def main():
         samples = world * threads * samples_per_thread * args.steps
         assert cnt["samples"] == samples, (cnt["samples"], samples)
         assert cnt["status"] == 0, "kernel reported an internal invariant violation"
+        # the reduced histogram holds exactly the increments every rank counted (timed region + the two
+        # scatter-timing launches after the clock): the N > 1 path validates itself on every run
+        all_incr = int(counters_all.cpu().numpy().view(np.uint64)[7])
         total_incr = int(hist.sum().item())
-        warm = args.warmup * threads * samples_per_thread  # histogram also holds the warm-up launches
-        # (it also holds the scatter-timing launches after the clock, extra_samples)
-        assert total_incr >= cnt["increments"] and (warm > 0 or extra_samples > 0 or total_incr == cnt["increments"])
+        assert total_incr == all_incr, "reduced histogram holds %d increments, the ranks counted %d" % (total_incr, all_incr)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         avg_flush_ms = sum(flush_ms) / len(flush_ms)
         # EXECUTED iterations: the reference's count minus what the exact-periodicity check retired early
@@ -330,7 +347,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic (seeded XORWOW sample stream, rocRAND-compatible, seed 1337)",
             "config": {
-                "workload": "C3: %dx%d canvas on [-2,2]^2, max_iter=%d, min_iter=%d" % (W, H, MAX_ITER, MIN_ITER),
+                "workload": "%s: %dx%d canvas on [-2,2]^2, max_iter=%d, min_iter=%d" % (args.config, W, H, MAX_ITER, MIN_ITER),
                 "threads_per_gpu": threads,
                 "samples_per_step_per_gpu": threads * samples_per_thread,
                 "passes_per_step": PASSES_PER_STEP,
@@ -345,8 +362,9 @@ def main():
             "iterations_per_sample": round((cnt["iterate_steps"] + cnt["replay_steps"]) / cnt["samples"], 3),
             "executed_iterations_per_sample": round(
                 (cnt["iterate_steps"] - cnt["skipped_steps"] + cnt["replay_steps"]) / cnt["samples"], 3),
-            "reference_equivalent_tflops": round(
-                (cnt["iterate_steps"] + cnt["replay_steps"]) * FLOPS_PER_ITERATION / elapsed / 1e12, 2),
+            # the one exchange of the path (after the clock): ranks in the communicator and its wall time
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "histogram_reduce_ms": round(reduce_ms, 3),
             "roofline": {
                 "bound": "valu_fp64",
                 "kernel": "draw_wave_kernel",

@@ -119,6 +119,15 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   return a;
 }
 
+// A draw call that launches nothing (no samples and nothing to drain) must still leave the workspace in the
+// state cb_flush_scatter expects -- an empty stream -- or the flush would re-add the previous launch's stream
+// (or read the counts of a workspace no kernel has written yet).
+int empty_stream_if_nothing_launches(const cb::DrawArgs &a, hipStream_t stream) {
+  const bool launches = a.n_threads != 0 && (a.samples_per_thread != 0 || (a.carry != nullptr && a.drain != 0));
+  if (launches || !a.bin.enabled) return 0;
+  return (int) hipMemsetAsync(a.bin.wave_count, 0, (size_t) a.bin.n_waves * sizeof(uint32_t), stream);
+}
+
 // Stream entries a launch is expected to produce: visited in-canvas points per sample are 0.4 (max_iter
 // 100) to 1.7 (max_iter 20000) on the full canvas; anything beyond the estimate falls back to atomics.
 constexpr double kEntriesPerSample = 2.5;
@@ -216,7 +225,14 @@ int finish(cb_renderer *r) {
     int rc = enqueue_launch(r, 0, r->carry_variant);
     if (rc) return rc;
   }
-  return sync_streams(r);
+  int rc = sync_streams(r);
+  if (rc) return rc;
+  // A kernel that saw one of its invariants broken (a queue ring overrun, a replay that does not end) has
+  // lost or duplicated samples: the histogram must not be taken for a result.
+  unsigned long long status = 0;
+  CB_TRY(hipMemcpyAsync(&status, &r->d_counters->status, sizeof(status), hipMemcpyDeviceToHost, r->stream));
+  CB_TRY(hipStreamSynchronize(r->stream));
+  return status ? CB_ERROR_KERNEL_INVARIANT : 0;
 }
 
 __global__ void __launch_bounds__(256) add_histogram_kernel(unsigned long long *dst,
@@ -282,31 +298,11 @@ int cb_abi_version(void) { return CB_ABI_VERSION; }
 
 const char *cb_error_string(int code) {
   if (code == 0) return "no error";
+  if (code == CB_ERROR_KERNEL_INVARIANT) {
+    return "the draw kernel reported a broken internal invariant (cb_counters.status): samples were lost";
+  }
   return hipGetErrorString((hipError_t) code);
 }
-
-int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg) {
-  const char *m = nullptr;
-  if (dims->w <= 0) {
-    m = "Output width must be positive.";
-  } else if (dims->h <= 0) {
-    m = "Output height must be positive.";
-  } else if (dims->max_real <= dims->min_real) {
-    m = "Maximum real value must be greater than minimum real value.";
-  } else if (dims->max_imag <= dims->min_imag) {
-    // (sic) the reference's wording, cudabrot.cu:520-521
-    m = "Minimum imaginary value must be greater than maximum imaginary value.";
-  }
-  if (m) {
-    if (msg) *msg = m;
-    return 0;
-  }
-  dims->delta_imag = (dims->max_imag - dims->min_imag) / ((double) dims->h);
-  dims->delta_real = (dims->max_real - dims->min_real) / ((double) dims->w);
-  return 1;
-}
-
-size_t cb_rng_state_bytes(uint32_t n_threads) { return (size_t) n_threads * 6u * sizeof(uint32_t); }
 
 int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
                       void *stream) {
@@ -357,6 +353,10 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   a.burning_ship = ship ? 1 : 0;
   if ((kernel_variant & CB_KERNEL_FLAG_DRAIN) && a.carry) a.drain = 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  {
+    int rc = empty_stream_if_nothing_launches(a, s);
+    if (rc) return rc;
+  }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
@@ -419,6 +419,10 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
     a.chan_max[j] = windows[j].max_escape_iterations;
   }
   if (base_variant == CB_KERNEL_FULL_ITERATE) a.check_periodic = 0;
+  {
+    int rc = empty_stream_if_nothing_launches(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc) return rc;
+  }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
   return (int) wave(a, false, reinterpret_cast<hipStream_t>(stream));
 }
@@ -553,12 +557,11 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
     if (rc) return rc;
     passes -= now;
   }
-  // The launches are complete when this returns; the orbits still in flight are carried to the next
-  // call and finished before anything reads the histogram or the counters (finish()).
-  {
-    int rc = sync_streams(r);
-    if (rc) return rc;
-  }
+  // The draw launches are complete when this returns (the fence at the end); the scatter of the last one may
+  // still be running on its own stream, so that the first draw launch of the next call starts beside it --
+  // a caller that renders in batches (the binary: every ~0.2 s) keeps the pipeline of enqueue_launch going
+  // across calls.  Everything that reads the histogram or the counters goes through finish(), which completes
+  // the carried orbits and waits for both streams.
   if (g_wave_dump) {  // diagnostic: write the per-wave records of the last launch
     (void) hipStreamSynchronize(r->stream);
     const size_t n = (size_t) cb::draw_wave_count(r->n_threads) * 8;
@@ -638,7 +641,7 @@ int cb_renderer_read_counters(cb_renderer *r, cb_counters *host_out) {
   CB_TRY(hipSetDevice(r->device));
   {
     int rc = finish(r);
-    if (rc) return rc;
+    if (rc && rc != CB_ERROR_KERNEL_INVARIANT) return rc;  // the counters are how a caller reads the status
   }
   CB_TRY(hipMemcpyAsync(host_out, r->d_counters, sizeof(cb_counters), hipMemcpyDeviceToHost,
                         r->stream));

@@ -7,8 +7,9 @@
 // is no CPU fallback, without a usable GPU the program prints the reference's error line and exits 1.
 //
 // Observable differences, all deliberate:
-//  * the -s buffer holds 64-bit counters (w*h*8 bytes); a reference-format file (w*h*4 bytes, uint32)
-//    is accepted on load and widened;
+//  * the -s buffer holds 64-bit counters behind a 32-byte header that names its own shape (magic, w, h, planes,
+//    counter width), so a file of another canvas can never be mistaken for this one's; a reference-format
+//    file (exactly w*h*4 bytes of uint32, no header) is accepted on load, announced, and widened;
 //  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
 //    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
 //  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "../../include/cudabrot_amd.h"
+#include "state_files.h"
 
 namespace {
 
@@ -381,145 +383,55 @@ class Run {
     }
   }
 
-  void load_inprogress() {  // cudabrot.cu:215-258
-    const char *path = cfg_.inprogress_file;
-    if (!path) return;
-    FILE *f = fopen(path, "rb");
-    printf("Loading previous image state from %s.\n", path);
-    if (!f) {
-      if (errno == ENOENT) {
-        printf("File %s doesn't exist yet. Not loading.\n", path);
-        return;
-      }
-      printf("Failed opening %s: %s\n", path, strerror(errno));
-      die();
-    }
-    // size check, cudabrot.cu:192-211,236-245
-    long size = -1;
-    if (fseek(f, 0, SEEK_END) != 0) {
-      printf("Failed seeking file end: %s\n", strerror(errno));
-      die();
-    }
-    if ((size = ftell(f)) < 0) {
-      printf("Failed reading file size: %s\n", strerror(errno));
-      die();
-    }
-    if (fseek(f, 0, SEEK_SET) != 0) {
-      printf("Failed seeking file start: %s\n", strerror(errno));
-      die();
-    }
-    const uint64_t narrow_bytes = pixel_count() * sizeof(uint32_t);
-    bool ok;
-    if ((uint64_t) size == narrow_bytes && cfg_.n_channels == 0) {
-      // written by the reference: uint32 counters, widened here
-      std::vector<uint32_t> narrow(pixel_count());
-      ok = fread(narrow.data(), narrow_bytes, 1, f) == 1;
-      for (uint64_t i = 0; ok && i < pixel_count(); i++) counts_[i] = narrow[i];
-    } else if ((uint64_t) size == buffer_bytes()) {
-      ok = fread(counts_, buffer_bytes(), 1, f) == 1;
-    } else {
-      printf("The size of %s doesn't match the expected size of %lu bytes.\n", path,
-             (unsigned long) buffer_bytes());
-      fclose(f);
-      die();
-    }
-    if (!ok) {
-      printf("Failed reading %s: %s\n", path, strerror(errno));
-      fclose(f);
-      die();
-    }
-    fclose(f);
-    CB_CHECK(cb_renderer_write_histogram(renderer_, counts_));
+  void load_inprogress() {  // cudabrot.cu:215-258; the file work is state_files.cpp's
+    if (!cfg_.inprogress_file) return;
+    const cb::FileResult res = cb::load_state_file(cfg_.inprogress_file, (uint32_t) cfg_.canvas.w, (uint32_t) cfg_.canvas.h,
+                                                   (uint32_t) planes(), counts_);
+    if (res == cb::FileResult::kError) die();
+    if (res == cb::FileResult::kOk) CB_CHECK(cb_renderer_write_histogram(renderer_, counts_));
   }
 
   void save_inprogress() {  // cudabrot.cu:262-280
-    const char *path = cfg_.inprogress_file;
-    if (!path) return;
-    printf("Saving in-progress buffer to %s.\n", path);
-    FILE *f = fopen(path, "wb");
-    if (!f) {
-      printf("Failed opening %s: %s\n", path, strerror(errno));
+    if (!cfg_.inprogress_file) return;
+    if (cb::save_state_file(cfg_.inprogress_file, (uint32_t) cfg_.canvas.w, (uint32_t) cfg_.canvas.h, (uint32_t) planes(),
+                            counts_) == cb::FileResult::kError) {
       die();
     }
-    if (fwrite(counts_, buffer_bytes(), 1, f) != 1) {
-      printf("Failed writing data to %s: %s\n", path, strerror(errno));
-      fclose(f);
-      die();
-    }
-    fclose(f);
   }
 
   // True-resume sidecar (extension, off unless --rng-state is given).  The -s buffer
   // is the histogram only, so the reference -- and this program by default -- replays seed 1337 from
-  // the start when it resumes (cudabrot.cu:179,215-258).  The sidecar keeps the generator states, so
-  // that buffer + sidecar continue the sample stream: P1 passes, save, resume, P2 passes gives the
-  // histogram of one run of P1 + P2 passes.
-  struct RngStateHeader {
-    char magic[8];  // "CBRNGST1"
-    uint64_t seed, first_subsequence, passes_done;
-    uint32_t n_threads, reserved;
-  };
+  // the start when it resumes (cudabrot.cu:179,215-258).  The sidecar keeps the generator states of every
+  // rank, so that buffer + sidecar continue the sample stream: P1 passes, save, resume, P2 passes gives the
+  // histogram of one run of P1 + P2 passes -- with --gpus N as well (N generators, the same N to resume).
   uint64_t passes_before_ = 0, passes_this_run_ = 0;
 
+  cb_renderer *rank_renderer(int r) { return r == 0 ? renderer_ : peers_[(size_t) r - 1]; }
+
   void load_rng_state() {
-    const char *path = cfg_.rng_state_file;
-    if (!path) return;
-    if (cfg_.gpus > 1) {
-      printf("--rng-state keeps one device's generator: not available with --gpus %d.\n", cfg_.gpus);
-      die();
+    if (!cfg_.rng_state_file) return;
+    std::vector<std::vector<unsigned char>> blobs;
+    const cb::FileResult res =
+        cb::load_rng_sidecar(cfg_.rng_state_file, cfg_.seed, CB_DEFAULT_THREADS, (uint32_t) cfg_.gpus,
+                             cb_rng_state_bytes(CB_DEFAULT_THREADS), &blobs, &passes_before_);
+    if (res == cb::FileResult::kError) die();
+    if (res != cb::FileResult::kOk) return;
+    for (int r = 0; r < cfg_.gpus; ++r) {
+      CB_CHECK(cb_renderer_write_rng_states(rank_renderer(r), blobs[(size_t) r].data()));
     }
-    FILE *f = fopen(path, "rb");
-    printf("Loading generator state from %s.\n", path);
-    if (!f) {
-      if (errno == ENOENT) {
-        printf("File %s doesn't exist yet. Not loading.\n", path);
-        return;
-      }
-      printf("Failed opening %s: %s\n", path, strerror(errno));
-      die();
-    }
-    const size_t bytes = cb_rng_state_bytes(CB_DEFAULT_THREADS);
-    RngStateHeader hd;
-    std::vector<unsigned char> blob(bytes + 1);
-    const bool ok = fread(&hd, sizeof(hd), 1, f) == 1 && memcmp(hd.magic, "CBRNGST1", 8) == 0 &&
-                    hd.seed == cfg_.seed && hd.first_subsequence == 0 &&
-                    hd.n_threads == CB_DEFAULT_THREADS &&
-                    fread(blob.data(), 1, bytes + 1, f) == bytes;  // exactly `bytes` left
-    fclose(f);
-    if (!ok) {
-      printf("%s is not a generator state for seed %lu and %u threads.\n", path,
-             (unsigned long) cfg_.seed, (unsigned) CB_DEFAULT_THREADS);
-      die();
-    }
-    passes_before_ = hd.passes_done;
-    printf("Continuing the sample stream after %lu passes.\n", (unsigned long) passes_before_);
-    CB_CHECK(cb_renderer_write_rng_states(renderer_, blob.data()));
   }
 
   void save_rng_state() {
-    const char *path = cfg_.rng_state_file;
-    if (!path) return;
-    printf("Saving generator state to %s.\n", path);
-    const size_t bytes = cb_rng_state_bytes(CB_DEFAULT_THREADS);
-    std::vector<unsigned char> blob(bytes);
-    CB_CHECK(cb_renderer_read_rng_states(renderer_, blob.data()));
-    RngStateHeader hd;
-    memset(&hd, 0, sizeof(hd));
-    memcpy(hd.magic, "CBRNGST1", 8);
-    hd.seed = cfg_.seed;
-    hd.passes_done = passes_before_ + passes_this_run_;
-    hd.n_threads = CB_DEFAULT_THREADS;
-    FILE *f = fopen(path, "wb");
-    if (!f) {
-      printf("Failed opening %s: %s\n", path, strerror(errno));
+    if (!cfg_.rng_state_file) return;
+    std::vector<std::vector<unsigned char>> blobs((size_t) cfg_.gpus,
+                                                  std::vector<unsigned char>(cb_rng_state_bytes(CB_DEFAULT_THREADS)));
+    for (int r = 0; r < cfg_.gpus; ++r) {
+      CB_CHECK(cb_renderer_read_rng_states(rank_renderer(r), blobs[(size_t) r].data()));
+    }
+    if (cb::save_rng_sidecar(cfg_.rng_state_file, cfg_.seed, CB_DEFAULT_THREADS, passes_before_ + passes_this_run_,
+                             blobs) == cb::FileResult::kError) {
       die();
     }
-    if (fwrite(&hd, sizeof(hd), 1, f) != 1 || fwrite(blob.data(), bytes, 1, f) != 1) {
-      printf("Failed writing data to %s: %s\n", path, strerror(errno));
-      fclose(f);
-      die();
-    }
-    fclose(f);
   }
 
   // The pass loop (cudabrot.cu:471-501).  Launch length follows the measured pass time so that the
@@ -540,41 +452,45 @@ class Run {
     CB_CHECK(cb_renderer_prepare(renderer_, variant));
     for (cb_renderer *p : peers_) CB_CHECK(cb_renderer_prepare(p, variant));
     const double t0 = wall_seconds();
-    // the pass loop of one rank; every rank follows the same clock / pass budget
-    auto pass_loop = [&](cb_renderer *r) -> long {
-      const double launch_seconds = 0.2;
-      long done = 0, next = 1;
-      while (!g_quit_requested) {
-        if (!by_clock) {
-          if (done >= cfg_.fixed_passes) break;
-          next = cfg_.fixed_passes - done;
-          if (next > 256) next = 256;
-        }
-        CB_CHECK(cb_renderer_render_passes(r, (uint32_t) next, variant));
-        done += next;
-        if (!by_clock) continue;
-        const double elapsed = wall_seconds() - t0;
-        if (cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run) break;
-        double budget = launch_seconds;
-        if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < budget) {
-          budget = cfg_.seconds_to_run - elapsed;
-        }
-        const double per_pass = elapsed / (double) done;
-        next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
-        if (next < 1) next = 1;
-        if (next > 4096) next = 4096;
-        if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
+    // The pass loop (one iteration = one batch of `next` reference passes on EVERY rank).  The main thread
+    // alone reads the clock and the quit flag and sizes the batches, so all ranks render the same number of
+    // passes -- an N-GPU run is the documented "N T threads for P passes" whether it ends by --passes, -t or
+    // Ctrl+C -- and a device error on any rank is reported here, after every worker has been joined.
+    const double launch_seconds = 0.2;
+    long done = 0, next = 1;  // passes per rank
+    std::vector<int> rank_rc((size_t) cfg_.gpus, 0);
+    while (!g_quit_requested) {
+      if (!by_clock) {
+        if (done >= cfg_.fixed_passes) break;
+        next = cfg_.fixed_passes - done;
+        if (next > 256) next = 256;
       }
-      return done;
-    };
-    std::vector<long> peer_done(peers_.size(), 0);
-    std::vector<std::thread> workers;
-    for (size_t k = 0; k < peers_.size(); ++k) {
-      workers.emplace_back([&, k] { peer_done[k] = pass_loop(peers_[k]); });
+      std::vector<std::thread> workers;
+      for (size_t k = 0; k < peers_.size(); ++k) {
+        workers.emplace_back([&, k] { rank_rc[k + 1] = cb_renderer_render_passes(peers_[k], (uint32_t) next, variant); });
+      }
+      rank_rc[0] = cb_renderer_render_passes(renderer_, (uint32_t) next, variant);
+      for (std::thread &w : workers) w.join();
+      for (int r = 0; r < cfg_.gpus; ++r) {
+        if (rank_rc[(size_t) r] != 0 && cfg_.gpus > 1) printf("GPU %d of %d:\n", r, cfg_.gpus);
+        CB_CHECK(rank_rc[(size_t) r]);
+      }
+      done += next;
+      if (!by_clock) continue;
+      const double elapsed = wall_seconds() - t0;
+      if (cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run) break;
+      double budget = launch_seconds;
+      if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < budget) {
+        budget = cfg_.seconds_to_run - elapsed;
+      }
+      const double per_pass = elapsed / (double) done;
+      next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
+      if (next < 1) next = 1;
+      if (next > 4096) next = 4096;
+      if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
     }
-    long done = pass_loop(renderer_);
-    for (std::thread &w : workers) w.join();
-    for (long d : peer_done) done += d;
+    passes_this_run_ = (uint64_t) done;  // per rank: what the generators have consumed
+    done *= cfg_.gpus;                   // reference-sized passes over all ranks
     if (!peers_.empty()) {  // the one exchange of the path: sum the shards onto rank 0
       std::vector<cb_renderer *> all(1, renderer_);
       all.insert(all.end(), peers_.begin(), peers_.end());
@@ -585,7 +501,6 @@ class Run {
     } else {
       CB_CHECK(cb_renderer_finish(renderer_));
     }
-    passes_this_run_ = (uint64_t) done;
     printf("%ld Buddhabrot passes took %f seconds.\n", done, wall_seconds() - t0);
     if (cfg_.print_stats) print_stats();
     if (cfg_.n_channels == 0) tone_map(0);

@@ -74,6 +74,16 @@ constexpr uint32_t kReplayBurst = 16;  // replay steps per asm burst
 constexpr uint32_t kBrentBits = 2;     // periodicity check: re-save when the chunk count has no bits below its top 2
 constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
 
+// The ring capacities are exact worst cases, not estimates: a stage runs only while its output ring can take
+// everything the stage may push (CB_STATUS_QUEUE_OVERFLOW guards the reasoning, these guard the constants).
+//   Q0: HEAD runs while q0_count < 64 and pushes at most 64                      -> 63 + 64
+//   Q1: MID runs while q1_count < kQ1Low and pushes at most 64                   -> kQ1Low - 1 + 64
+//   Q2: LONG runs while q2_count + replaying < 64 and one chunk can retire every orbit slot of the wave
+//       (64 lanes x kOrbitsPerLane)                                              -> 63 + 64 * kOrbitsPerLane
+static_assert(kQ0Cap >= 63 + 64, "Q0 must hold a full HEAD pass on top of 63 queued survivors");
+static_assert(kQ1Cap >= kQ1Low - 1 + 64, "Q1 must hold a full MID pass on top of kQ1Low - 1 queued orbits");
+static_assert(kQ2Cap >= 63 + 64 * kOrbitsPerLane, "Q2 must hold every orbit slot of a chunk on top of 63 queued points");
+
 struct WaveQueues {
   double q0_cr[kQ0Cap], q0_ci[kQ0Cap];
   double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];

@@ -77,6 +77,10 @@ typedef struct {
 
 #define CB_STATUS_QUEUE_OVERFLOW 1u
 #define CB_STATUS_REPLAY_RUNAWAY 2u
+/* Returned (instead of a hipError_t) by cb_renderer_finish and by everything that reads a renderer's histogram
+ * or image when cb_counters.status is nonzero: a draw kernel saw one of its internal invariants broken and has
+ * lost samples, so the histogram is not a result.  cb_renderer_read_counters still succeeds and shows the flags. */
+#define CB_ERROR_KERNEL_INVARIANT 100001
 
 /* Kernel variants of cb_draw_buddhabrot. */
 #define CB_KERNEL_DEFAULT 0 /* wave-scheduled four-stage kernel (the product path)                */
@@ -149,7 +153,9 @@ size_t cb_carry_bytes(uint32_t n_threads);
 /* Second half of the scatter: partitions the pixel stream a cb_draw_buddhabrot call left in
  * d_workspace by 128x128-pixel tile (counting sort) and adds every tile to d_hist from an LDS
  * histogram with coalesced atomics.  Same dims, n_threads, d_workspace and workspace_bytes as that
- * call.  A no-op for a workspace the draw call could not use. */
+ * call.  A no-op for a workspace the draw call could not use.  Precondition: the workspace was last written by
+ * a cb_draw_buddhabrot call with these arguments (a call that launches nothing -- no samples, nothing to
+ * drain -- leaves an empty stream); flushing a workspace no draw call has touched is undefined. */
 int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32_t n_threads,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 
@@ -192,9 +198,10 @@ int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_
                                 const cb_iteration_control *windows, int n_channels, uint64_t seed,
                                 uint64_t first_subsequence, uint32_t n_threads);
 /* `passes` iterations of the loop body of RenderImage (cudabrot.cu:483-487), fused into as few
- * launches as possible; returns after the device has finished them.  Orbits still in flight are
+ * launches as possible; returns after the device has finished the draw launches (the scatter of the last one
+ * may still be running, beside which the next call's first launch starts).  Orbits still in flight are
  * carried to the next call; cb_renderer_finish (called by the read/write functions below) completes
- * them. */
+ * them and waits for everything. */
 int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_variant);
 /* Optional, before the first cb_renderer_render_passes: allocates now what that call would allocate for
  * this kernel variant (the scatter workspaces: tens of GB on a large canvas), so that a caller who times

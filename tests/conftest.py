@@ -39,3 +39,22 @@ def golden():
 
     with open(os.path.join(ROOT, "tests", "golden", "appendix_b.json")) as f:
         return json.load(f)
+
+
+STATE_HEADER_BYTES = 32
+
+
+def read_state_file(path, h, w, planes=1):
+    """The binary's -s file: a 32-byte header {"CBHIST64", u32 w, h, planes, counter bytes, u64 0} and then
+    planes x h x w native-endian u64 counters, row 0 = min_imag (cli_main.cpp, StateHeader).  Returns the
+    counters as [h, w] (planes == 1) or [planes, h, w]."""
+    import numpy as np
+
+    with open(path, "rb") as f:
+        head = f.read(STATE_HEADER_BYTES)
+        body = np.fromfile(f, dtype=np.uint64)
+    assert head[:8] == b"CBHIST64", head[:8]
+    fields = np.frombuffer(head[8:24], dtype=np.uint32)
+    assert tuple(int(v) for v in fields) == (w, h, planes, 8), fields
+    assert body.size == planes * h * w
+    return body.reshape(h, w) if planes == 1 else body.reshape(planes, h, w)

@@ -10,6 +10,8 @@ import time
 import numpy as np
 import pytest
 
+from conftest import STATE_HEADER_BYTES, read_state_file
+
 pytestmark = pytest.mark.gpu
 
 T = 512 * 512  # the CLI always runs the reference's 512 x 512 threads (cudabrot.cu:20,23)
@@ -54,7 +56,7 @@ def test_fixed_pass_run_matches_oracle_byte_for_byte(exe, oracle, small_render, 
     assert lines[10] == "Done! Output image saved: %s" % out
     with open(out, "rb") as f:
         assert f.read() == oracle.encode_pgm(gray)
-    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)   # raw native-endian u64[h][w]
+    state = read_state_file(buf, 200, 300)   # header + native-endian u64[h][w]
     assert np.array_equal(state, hist)
 
 
@@ -67,7 +69,7 @@ def test_resume_adds_to_the_saved_buffer(exe, small_render, tmp_path):
     r = run(exe, *args)
     assert r.returncode == 0
     assert "doesn't exist yet" not in r.stdout
-    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)
+    state = read_state_file(buf, 200, 300)
     assert np.array_equal(state, 2 * small_render[0])
 
 
@@ -84,7 +86,7 @@ def test_rng_state_sidecar_continues_the_sample_stream(exe, oracle, tmp_path):
     assert r2.returncode == 0
     assert "Continuing the sample stream after 2 passes." in r2.stdout
     three, _ = oracle.render(300, 200, 200, 20, T, 3, omp_threads=0)
-    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)
+    state = read_state_file(buf, 200, 300)
     assert np.array_equal(state, three)
     # a sidecar for another seed is refused
     r3 = run(exe, "--passes", "1", "--seed", "99", *common)
@@ -97,7 +99,7 @@ def test_burning_ship_flag(exe, oracle, tmp_path):
     r = run(exe, "--passes", "1", "--burning-ship", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
     assert r.returncode == 0
     hist, _ = oracle.render(300, 200, 200, 20, T, 1, burning_ship=True, omp_threads=0)
-    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+    assert np.array_equal(read_state_file(buf, 200, 300), hist)
 
 
 def test_channel_flags_render_the_colour_recipe_in_one_run(exe, oracle, tmp_path):
@@ -112,7 +114,7 @@ def test_channel_flags_render_the_colour_recipe_in_one_run(exe, oracle, tmp_path
     r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-g", "2.2", "-s", buf, *args)
     assert r.returncode == 0, r.stdout
     assert "Creating 300x200 image, 1500 max iterations." in r.stdout
-    planes = np.fromfile(buf, dtype=np.uint64).reshape(3, 200, 300)
+    planes = read_state_file(buf, 200, 300, planes=3)
     for j, ((m, c), o) in enumerate(zip(windows, outs)):
         hist, _ = oracle.render(300, 200, m, c, T, 2, omp_threads=0)
         assert np.array_equal(planes[j], hist)
@@ -135,7 +137,7 @@ def test_gpus_flag_shards_the_subsequences_and_sums_once(exe, oracle, tmp_path):
     assert r.returncode == 0, r.stdout
     assert re.search(r"^6 Buddhabrot passes took", r.stdout, re.M)          # 3 ranks x 2 passes
     hist, cnt = oracle.render(300, 200, 200, 20, 3 * T, 2, omp_threads=0)
-    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+    assert np.array_equal(read_state_file(buf, 200, 300), hist)
     import json
     stats = json.loads(r.stderr.strip().splitlines()[-1])
     assert stats["samples"] == cnt["samples"] and stats["increments"] == cnt["increments"] and stats["status"] == 0
@@ -147,7 +149,7 @@ def test_seed_flag_selects_another_sample_stream(exe, oracle, tmp_path, seed):
     r = run(exe, "--passes", "1", "--seed", str(seed), "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
     assert r.returncode == 0
     hist, _ = oracle.render(300, 200, 200, 20, T, 1, seed=seed, omp_threads=0)
-    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), hist)
+    assert np.array_equal(read_state_file(buf, 200, 300), hist)
 
 
 def test_reference_format_u32_buffer_is_accepted_and_widened(exe, small_render, tmp_path):
@@ -156,8 +158,51 @@ def test_reference_format_u32_buffer_is_accepted_and_widened(exe, small_render, 
     base.tofile(buf)                                   # what the reference writes: uint32[h][w]
     r = run(exe, "--passes", "2", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf)
     assert r.returncode == 0
-    state = np.fromfile(buf, dtype=np.uint64).reshape(200, 300)   # rewritten as u64
+    assert "%s has no header and the size of 32-bit counters: read as the reference's format." % buf in r.stdout
+    state = read_state_file(buf, 200, 300)   # rewritten in the native format: header + u64
     assert np.array_equal(state, base.astype(np.uint64) + small_render[0])
+
+
+def test_native_buffer_of_another_canvas_is_refused_even_at_the_reference_size(exe, tmp_path):
+    """A native (u64) buffer of HALF the pixel count has exactly w*h*4 bytes of payload for this canvas: the
+    format is decided by the header, never by the size, so it is refused with the reference's size-mismatch
+    line (cudabrot.cu:239-245) instead of being read as 32-bit counters."""
+    buf = str(tmp_path / "half.bin")
+    assert run(exe, "--passes", "1", "-w", "300", "-h", "100", "-m", "100", "-o", os.devnull, "-s", buf).returncode == 0
+    size = os.path.getsize(buf)
+    assert size == STATE_HEADER_BYTES + 300 * 100 * 8
+    r = run(exe, "--passes", "1", "-w", "300", "-h", "200", "-m", "100", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 1
+    assert "%s holds a 300x100 buffer of 1 plane(s), 8-byte counters" % buf in r.stdout
+    assert "The size of %s doesn't match the expected size of %d bytes." % (buf, STATE_HEADER_BYTES + 300 * 200 * 8) in r.stdout
+    assert os.path.getsize(buf) == size                                # left untouched
+    # the same payload WITHOUT the header is, by its size, a reference file of the 300 x 200 canvas: accepted
+    with open(buf, "rb") as f:
+        payload = f.read()[STATE_HEADER_BYTES:]
+    with open(buf, "wb") as f:
+        f.write(payload)
+    r = run(exe, "--passes", "0", "-w", "300", "-h", "200", "-m", "100", "-o", os.devnull, "-s", buf)
+    assert r.returncode == 0 and "read as the reference's format" in r.stdout
+    assert np.array_equal(read_state_file(buf, 200, 300), np.frombuffer(payload, dtype=np.uint32).reshape(200, 300))
+
+
+def test_rng_state_sidecar_with_several_gpus(exe, oracle, tmp_path):
+    """True resume with --gpus N (SURVEY.md 8f N3 + 8e): the sidecar keeps every rank's generator, so 2 ranks x
+    (2 + 1) passes in two runs == one run of 2 T threads x 3 passes; a sidecar of another rank count is refused.
+    Every rank on device 0 here (CUDABROT_AMD_FAKE_GPUS); tests/test_gpu_multi.py runs it on real devices."""
+    env = dict(os.environ, CUDABROT_AMD_FAKE_GPUS="1")
+    buf, side = str(tmp_path / "m.bin"), str(tmp_path / "m.rng")
+    common = ["--gpus", "2", "-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf, "--rng-state", side]
+    r1 = run(exe, "--passes", "2", *common, env=env)
+    assert r1.returncode == 0, r1.stdout
+    assert re.search(r"^4 Buddhabrot passes took", r1.stdout, re.M)
+    r2 = run(exe, "--passes", "1", *common, env=env)
+    assert r2.returncode == 0, r2.stdout
+    assert "Continuing the sample stream after 2 passes." in r2.stdout
+    three, _ = oracle.render(300, 200, 200, 20, 2 * T, 3, omp_threads=0)
+    assert np.array_equal(read_state_file(buf, 200, 300), three)
+    r3 = run(exe, "--passes", "1", "--gpus", "3", *common[2:], env=env)
+    assert r3.returncode == 1 and "is not a generator state for seed 1337, 262144 threads and 3 GPU(s)." in r3.stdout
 
 
 def test_buffer_size_mismatch_is_an_error(exe, tmp_path):
@@ -166,7 +211,7 @@ def test_buffer_size_mismatch_is_an_error(exe, tmp_path):
         f.write(b"\0" * 1000)
     r = run(exe, "--passes", "1", "-w", "300", "-h", "200", "-o", os.devnull, "-s", buf)
     assert r.returncode == 1                                           # cudabrot.cu:239-245
-    assert "The size of %s doesn't match the expected size of %d bytes." % (buf, 300 * 200 * 8) in r.stdout
+    assert "The size of %s doesn't match the expected size of %d bytes." % (buf, STATE_HEADER_BYTES + 300 * 200 * 8) in r.stdout
     assert os.path.getsize(buf) == 1000                                # left untouched
 
 
@@ -219,7 +264,7 @@ def test_sigint_finishes_the_pass_and_still_saves(exe, tmp_path):
     assert "Signal 2 received, waiting for current pass to finish..." in stdout
     assert "Done! Output image saved: %s" % out in stdout
     assert os.path.getsize(out) == len(b"P5\n256 256\n65535\n") + 256 * 256 * 2
-    assert os.path.getsize(buf) == 256 * 256 * 8
+    assert os.path.getsize(buf) == STATE_HEADER_BYTES + 256 * 256 * 8
 
 
 def test_invalid_device_reports_like_the_reference_and_exits_one(exe):

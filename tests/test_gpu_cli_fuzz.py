@@ -10,6 +10,8 @@ import time
 import numpy as np
 import pytest
 
+from conftest import read_state_file
+
 pytestmark = pytest.mark.gpu
 
 T = 512 * 512
@@ -83,7 +85,7 @@ def test_random_command_lines_against_the_oracle(repo_root, oracle, tmp_path):
                                 burning_ship=t["ship"])
         hist = hist * np.uint64(runs)     # a resumed run replays the same stream on top
         gray, mx, _ = oracle.set_grayscale_pixels(hist, 1.0 if t["g"] is None else t["g"])
-        state = np.fromfile(buf, dtype=np.uint64).reshape(t["h"], t["w"])
+        state = read_state_file(buf, t["h"], t["w"])
         assert np.array_equal(state, hist), "histogram differs: %r" % (t,)
         with open(out, "rb") as f:
             assert f.read() == oracle.encode_pgm(gray), "image differs (same histogram, max %d): %r" % (mx, t)
