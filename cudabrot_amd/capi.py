@@ -144,6 +144,7 @@ def _load():
         "cb_rng_state_bytes": (C.c_size_t, [u32]),
         "cb_initialize_rng": (i32, [u64, u64, u32, vp, vp]),
         "cb_scatter_workspace_bytes": (C.c_size_t, [dims_p, u32, u32]),
+        "cb_scatter_workspace_bytes_channels": (C.c_size_t, [dims_p, i32, u32, u32]),
         "cb_draw_buddhabrot": (i32, [dims_p, vp, it_p, vp, u32, u32, vp, i32, vp, C.c_size_t, vp, vp]),
         "cb_carry_bytes": (C.c_size_t, [u32]),
         "cb_draw_buddhabrot_channels": (i32, [dims_p, vp, it_p, i32, vp, u32, u32, vp, i32, vp, C.c_size_t, vp, vp]),
@@ -180,7 +181,7 @@ def _load():
 lib = _load()
 EXPORTED_SYMBOLS = (
     "cb_abi_version cb_error_string cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
-    "cb_scatter_workspace_bytes cb_carry_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create "
+    "cb_scatter_workspace_bytes cb_scatter_workspace_bytes_channels cb_carry_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create "
     "cb_renderer_render_passes cb_renderer_finish "
     "cb_renderer_read_histogram "
     "cb_renderer_write_histogram cb_renderer_read_counters cb_renderer_device_histogram "
@@ -216,9 +217,10 @@ def initialize_rng(seed, first_subsequence, n_threads, d_states, stream=0):
     _check(lib.cb_initialize_rng(seed, first_subsequence, n_threads, d_states, stream), "cb_initialize_rng")
 
 
-def scatter_workspace_bytes(dims, n_threads, samples_per_thread):
-    """Suggested scatter-workspace size for launches of this shape (0: the canvas cannot use one)."""
-    return int(lib.cb_scatter_workspace_bytes(C.byref(dims), n_threads, samples_per_thread))
+def scatter_workspace_bytes(dims, n_threads, samples_per_thread, n_channels=1):
+    """Suggested scatter-workspace size for launches of this shape (0: the canvas cannot use one);
+    n_channels > 1: for a fused multi-channel launch of that many planes."""
+    return int(lib.cb_scatter_workspace_bytes_channels(C.byref(dims), n_channels, n_threads, samples_per_thread))
 
 
 def carry_bytes(n_threads):

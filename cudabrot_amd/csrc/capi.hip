@@ -321,19 +321,19 @@ size_t cb_carry_bytes(uint32_t n_threads) {
          (size_t) cb::kSchedWords * sizeof(uint32_t);
 }
 
+size_t cb_scatter_workspace_bytes_channels(const cb_fractal_dimensions *dims, int n_channels, uint32_t n_threads,
+                                           uint32_t samples_per_thread) {
+  if (!dims || dims->w <= 0 || dims->h <= 0 || n_threads == 0 || samples_per_thread == 0) return 0;
+  if (n_channels < 1 || n_channels > CB_MAX_CHANNELS) return 0;
+  const uint32_t n_waves = cb::draw_wave_count(n_threads);
+  // every plane of a fused launch receives its own share of the visited points
+  const double entries = (double) n_threads * (double) samples_per_thread * kEntriesPerSample * (n_channels > 1 ? 1.5 : 1.0);
+  return cb::bin_workspace_bytes(dims->w, dims->h, n_waves, entries / n_waves, n_channels);
+}
+
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
                                   uint32_t samples_per_thread) {
-  if (!dims || dims->w <= 0 || dims->h <= 0 || n_threads == 0 || samples_per_thread == 0) return 0;
-  const uint32_t n_waves = cb::draw_wave_count(n_threads);
-  const double entries = (double) n_threads * (double) samples_per_thread * kEntriesPerSample;
-  // large enough for a fused launch of up to CB_MAX_CHANNELS planes too (their tiles are sorted as one
-  // canvas: a longer count matrix, the same stream)
-  size_t best = 0;
-  for (int planes = 1; planes <= CB_MAX_CHANNELS; ++planes) {
-    const size_t b = cb::bin_workspace_bytes(dims->w, dims->h, n_waves, entries / n_waves, planes);
-    if (b > best) best = b;
-  }
-  return best;
+  return cb_scatter_workspace_bytes_channels(dims, 1, n_threads, samples_per_thread);
 }
 
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
@@ -515,8 +515,8 @@ void prepare_for_variant(cb_renderer *r, int kernel_variant) {
       getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
     // scatter workspace for the largest launch render_passes makes; on any failure: direct atomics
     r->workspace_tried = 1;
-    size_t want = cb_scatter_workspace_bytes(&r->dims, r->n_threads,
-                                             max_passes_per_launch() * CB_SAMPLES_PER_THREAD);
+    size_t want = cb_scatter_workspace_bytes_channels(&r->dims, r->n_channels > 0 ? r->n_channels : 1, r->n_threads,
+                                                      max_passes_per_launch() * CB_SAMPLES_PER_THREAD);
     size_t free_b = 0, total_b = 0;
     if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       if (want > free_b / 4) want = free_b / 4;

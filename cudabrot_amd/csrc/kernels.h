@@ -23,34 +23,36 @@ void seed_state(uint64_t seed, uint32_t x[5], uint32_t *d);
 // each), which caps every configuration of this path.  With a workspace, the REPLAY stage therefore
 // does not touch the histogram: each wave appends the visited pixels as packed (row << 16 | col)
 // words to its own region of a stream in HBM (coalesced stores).  After the draw kernel the stream is
-// partitioned by 128x128-pixel tile with a counting sort (count per (wave, tile) -> exclusive scan
-// -> scatter of 14-bit in-tile offsets, no atomics, deterministic), and one workgroup per tile
-// accumulates its bucket in an LDS histogram and adds the tile to the u64 histogram with coalesced
-// atomics: one 64-byte request per 8 pixels per launch instead of one per increment.
+// cut into REGIONS of 32768 entries; every region is sorted by 128x128-pixel tile on its own, inside one
+// workgroup's LDS (no counting pass over the stream, no global prefix sums: the only thing a region
+// publishes is where each tile's run starts inside it), and one workgroup per (tile, slice of regions)
+// then gathers that tile's runs from the regions, accumulates them in an LDS histogram and adds the tile
+// to the u64 histogram with coalesced atomics: one 64-byte request per 8 pixels per slice instead of one
+// per increment.
 constexpr int kTileShift = 7;
 constexpr int kTileSize = 1 << kTileShift;          // 128 x 128 pixels
 constexpr int kTilePixels = kTileSize * kTileSize;  // 16384 u32 counters = 64 KiB of LDS
-constexpr uint32_t kMaxTiles = 4096;                // one sorting level up to here (8192 x 8192 pixels)
+constexpr uint32_t kGroupTiles = 1024;              // keys of one region sort; more tiles: two levels
 constexpr uint32_t kMinRegionEntries = 4096;        // below this per wave the workspace is not used
 
 struct BinLayout {
   uint32_t enabled;     // 0: REPLAY adds to the histogram directly
-  uint32_t n_waves;     // regions in the stream (= waves of the draw kernel)
-  uint32_t cap;         // entries per wave region (multiple of 4)
+  uint32_t n_waves;     // segments of the stream (= waves of the draw kernel)
+  uint32_t cap;         // entries per wave segment (multiple of 8)
   uint32_t n_tiles;     // n_planes * tiles_x * tiles_y
   uint32_t tiles_x;
-  uint32_t slice_entries;  // entries one accumulate workgroup takes
-  // more than kMaxTiles tiles: the stream is first partitioned into groups of 1024 tiles (level A),
-  // then every fixed-size region of the grouped stream is sorted by tile (level B); scatter.hip
+  uint32_t slice_regions;  // regions one accumulate workgroup gathers from
+  // more than kGroupTiles tiles: the stream is first partitioned into groups of 1024 consecutive tiles
+  // (level A: count -> scan -> scatter of whole words into `grouped`), and the regions are cut from each
+  // group's stretch of `grouped`, so that a region holds tiles of one group only; scatter.hip
   uint32_t two_level;
-  uint32_t n_groups;
-  uint32_t max_regions;   // size of the region table (level B; = n_waves with one level)
-  uint32_t count_stride;  // row length of `count`
+  uint32_t n_groups;    // 1 with one level
+  uint32_t max_regions;   // size of the region table and row length of run_start
   // Layout of a stream word: col in the low bits, row above it (e_row_shift), and -- fused multi-channel
   // renders only -- the index of the channel (plane) the point goes to above both (e_chan_shift,
   // e_chan_mask; 0 / 0 with one plane).  One channel: row << 16 | col.  The planes are sorted as ONE
   // canvas of n_planes * tiles_y tile rows: tile index = (plane * tiles_y + tile row) * tiles_x + tile
-  // column, n_tiles = n_planes * tiles_x * tiles_y, so one count -> sort -> accumulate serves all planes.
+  // column, n_tiles = n_planes * tiles_x * tiles_y, so one sort -> accumulate serves all planes.
   uint32_t e_row_shift, e_col_mask, e_row_mask, e_chan_shift, e_chan_mask;
   uint32_t n_planes, tiles_y;
   unsigned long long plane_pixels;  // w * h: distance between the planes of the histogram
@@ -59,16 +61,15 @@ struct BinLayout {
   uint32_t *a_count;              // [n_groups*replicas][n_waves]  level A counts, then prefix over waves
   unsigned long long *a_base;     // [n_groups*replicas + 1]  level A exclusive prefix over keys
   uint32_t *grouped;              // [n_waves * cap]      the stream, grouped (two levels)
-  unsigned long long *region_start;  // [max_regions]     regions of the (grouped) stream ...
-  uint32_t *region_count;         // [max_regions]
-  uint32_t *region_group;         // [max_regions]        ... their group
-  uint32_t *region_index;         // [max_regions]        ... and index inside the group
-  uint32_t *group_regions;        // [n_groups]           regions per group
+  unsigned long long *region_start;  // [max_regions]     regions of the (grouped) stream: first entry ...
+  uint32_t *region_count;         // [max_regions]        ... entries (<= 32768) ...
+  uint32_t *region_group;         // [max_regions]        ... and group (0 with one level)
+  uint32_t *group_first;          // [n_groups]           a group's regions are consecutive: the first ...
+  uint32_t *group_regions;        // [n_groups]           ... and how many
   uint32_t *n_regions;            // [1]
-  uint32_t *count;                // [n_tiles][count_stride]  counts, then exclusive prefix over regions
-  unsigned long long *tile_base;  // [n_tiles + 1]        exclusive prefix over tiles
-  uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate slices
-  uint16_t *sorted;               // [n_waves * cap]      in-tile offsets grouped by tile
+  uint16_t *run_start;            // [min(n_tiles, 1024)][max_regions]  where tile k0 + i's run starts in a region
+  uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate workgroups per tile
+  uint16_t *sorted;               // [n_waves * cap]      in-tile offsets, every region sorted by tile in place
 };
 
 // Bytes of a workspace for launches that write about entries_per_wave stream entries per wave (0 if
@@ -77,7 +78,7 @@ size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wa
 // Carves `bytes` at `workspace` into a BinLayout (enabled = 0 if it is too small or the canvas does
 // not qualify).
 BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t n_waves, int n_channels = 0);
-// count -> scan -> scatter -> accumulate on `stream`, after the draw kernel that filled the stream.
+// region sort -> gather + accumulate on `stream`, after the draw kernel that filled the stream.
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream);
 

@@ -1,32 +1,33 @@
 // scatter.hip -- the deferred, tile-binned scatter (see kernels.h, BinLayout).
 //
-// Input: the pixel stream the REPLAY stage of draw_wave_kernel wrote -- per wave a region of packed
+// Input: the pixel stream the REPLAY stage of draw_wave_kernel wrote -- per wave a segment of packed
 // (row << 16 | col) words.  Output: the same increments added to the u64 histogram, with one
 // 64-byte memory-side request per 8 pixels of a tile slice instead of one per increment.
 //
-// One level (canvases of up to 4096 tiles of 128 x 128 pixels):
-//   count      one workgroup per region (= wave region of the stream): LDS histogram over tiles
-//              -> count[tile][region]
-//   scan_rows  one workgroup per tile: exclusive prefix over its regions (in place), tile total
-//   scan_keys  exclusive prefix over the tile totals -> tile_base[]; and over the number of
-//              accumulate slices per tile -> slice_base[]
-//   scatter    one workgroup per region, chunks of 8192 entries: rank inside (chunk, tile) by LDS
-//              atomics, sort the chunk in LDS, write each tile's run to its place in `sorted` as
-//              14-bit in-tile offsets (consecutive lanes write consecutive places of a run)
-//   accumulate one workgroup per slice (a stretch of one tile's entries): LDS u32 histogram of the
-//              slice, then added to the u64 histogram with coalesced device-scope atomics.  Hot
-//              tiles are many slices, so the grid stays balanced.
+// One level (canvases of up to 1024 tiles of 128 x 128 pixels; C2 / C3: exactly 1024):
+//   regions     the stream is cut into regions of at most 32768 entries (a wave's segment = consecutive
+//               regions); one small kernel makes the table
+//   region_sort one workgroup per region: the region's entries are read ONCE (32 per thread, kept in
+//               registers), counted per tile in LDS, the 1024 counts are scanned, the entries are ranked
+//               with LDS atomics and written -- as 14-bit in-tile offsets -- into a sorted image of the
+//               region in LDS, which goes out as one linear, fully coalesced block.  The only other thing
+//               a region publishes is run_start[tile][region]: where each tile's run begins inside it.
+//               No pass over the stream that only counts, no global prefix sums, no fragmentary writes
+//               (the previous design placed every tile's entries contiguously in a global order: one pass
+//               to count, two scans, and a scatter whose runs were 8 entries = 16 bytes long).
+//   accumulate  one workgroup per (tile, slice of 4096 regions): each LANE walks one region's run of the
+//               tile (~32 entries = 64 bytes, 16-byte loads), `ds_add_u32` into a 64 KiB LDS tile, then one
+//               coalesced pass of device-scope atomics over the non-zero pixels.
 //
-// Two levels (up to 262144 tiles: 20000 x 20000 and beyond).  With more tiles than LDS counters, or
-// runs too short to coalesce, the stream is first partitioned into GROUPS of 1024 consecutive
-// tiles by the same count -> scan -> scatter (level A: the key is group * 16 + a lane-derived
-// replica, which spreads the LDS atomics over 4 counters per group; whole 4-byte entries are
-// moved).  The grouped stream is then cut into fixed-size regions and every region runs the
-// one-level pipeline over the 1024 tiles of its group (level B).
+// Two levels (up to 262144 tiles: 20000 x 20000 and beyond, or the planes of a fused render together).  A
+// region sort has 1024 keys, so the stream is first partitioned into GROUPS of 1024 consecutive tiles by
+// a counting sort over the wave segments (level A: count -> scan -> scatter of whole 4-byte words into
+// `grouped`; the key is group * 4 + a replica derived from the entry's index, which spreads the LDS
+// atomics).  Regions are then cut from each group's stretch of `grouped`, so every region holds tiles of
+// one group, and the two kernels above run unchanged with the group's first tile as key 0.
 //
-// Everything is a counting sort: no global atomics before the final flush, and the bytes written are
-// the same from run to run.  All of it is HBM-streaming work (4 + 4 + 4 + 2 + 2 = 16 bytes per
-// increment end to end with one level, 28 with two, plus 16 KiB of flush per slice).
+// Increments commute, so the histogram is the same whatever the order; nothing here depends on timing
+// except the order of entries inside a run, which nothing reads.
 #include <stdlib.h>
 #include <string.h>
 
@@ -36,17 +37,21 @@ namespace cb {
 
 namespace {
 
-constexpr uint32_t kScatterThreads = 512;
-constexpr uint32_t kChunkEntries = 8192;  // 16 per thread
+constexpr uint32_t kScatterThreads = 512;          // level A
+constexpr uint32_t kChunkEntries = 8192;           // level A: 16 per thread
 constexpr uint32_t kPerThread = kChunkEntries / kScatterThreads;
-constexpr uint32_t kSliceEntriesDefault = 262144;  // entries one accumulate workgroup takes: few enough
-                                                    // flushes of the 64 KiB tile, many enough slices to balance
 constexpr uint32_t kAccThreads = 512;
-constexpr uint32_t kGroupTiles = 1024;             // tiles per group (two levels)
 constexpr uint32_t kGroupShift = 10;
+static_assert((1u << kGroupShift) == kGroupTiles, "group = tile >> kGroupShift");
 constexpr uint32_t kReplicas = 4;                  // level-A keys per group (2..8 measured equal at 20000^2; 16: 5 % slower, 64: 15 %)
 constexpr uint32_t kMaxGroups = 256;               // -> 262144 tiles (all planes of a fused render together)
-constexpr uint32_t kRegionEntries = 262144;        // level-B region: 32 chunks
+constexpr uint32_t kMaxKeys = kMaxGroups * kGroupTiles;
+constexpr uint32_t kRegionEntries = 32768;         // entries of one region sort: runs of ~32 entries per tile
+constexpr uint32_t kSortThreads = 1024;
+constexpr uint32_t kSortPerThread = kRegionEntries / kSortThreads;  // 32 entries in registers
+constexpr uint32_t kSliceRegionsDefault = 4096;    // regions one accumulate workgroup gathers from
+constexpr uint32_t kGroupRegionEntries = kRegionEntries - 8u;  // regions cut from a group's stretch (two levels)
+static_assert(kRegionEntries <= 65535, "run_start holds 16-bit positions inside a region");
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -64,54 +69,10 @@ __device__ __forceinline__ uint32_t offset_of(uint32_t e, const BinLayout &b) {
 __device__ __forceinline__ void lds_inc(uint32_t *p) {
   __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_u32
 }
-
-// What a sorting pass works on.  kLevelA: wave regions of the stream -> keys (group, replica) ->
-// `grouped`.  Otherwise (level B, or the only level): regions of the (grouped) stream -> tiles of the
-// region's group -> `sorted`.
-template <bool kLevelA>
-struct Pass {
-  __device__ static uint32_t n_regions(const BinLayout &b) { return kLevelA ? b.n_waves : *b.n_regions; }
-  __device__ static const uint32_t *src(const BinLayout &b, uint32_t r) {
-    if (kLevelA) return b.stream + (size_t) r * b.cap;
-    return (b.two_level ? b.grouped : b.stream) + b.region_start[r];
-  }
-  __device__ static uint32_t count_of(const BinLayout &b, uint32_t r) {
-    return kLevelA ? b.wave_count[r] : b.region_count[r];
-  }
-  __device__ static uint32_t n_keys(const BinLayout &b) {
-    if (kLevelA) return b.n_groups * kReplicas;
-    return b.two_level ? kGroupTiles : b.n_tiles;
-  }
-  // first global key of region r's key range, and the region's column in the count matrix
-  __device__ static uint32_t key0(const BinLayout &b, uint32_t r) {
-    return (kLevelA || !b.two_level) ? 0u : b.region_group[r] << kGroupShift;
-  }
-  __device__ static uint32_t column(const BinLayout &b, uint32_t r) {
-    return (kLevelA || !b.two_level) ? r : b.region_index[r];
-  }
-  // j: the entry's index in its region.  The replica must be a function of the entry alone (both the
-  // count and the scatter kernel evaluate it, with different thread mappings).
-  __device__ static uint32_t key(const BinLayout &b, uint32_t e, uint32_t k0, uint32_t j) {
-    const uint32_t t = tile_of(e, b);
-    if (kLevelA) return ((t >> kGroupShift) * kReplicas) | (j & (kReplicas - 1u));
-    return t - k0;
-  }
-  __device__ static uint32_t *counts(const BinLayout &b) { return kLevelA ? b.a_count : b.count; }
-  __device__ static unsigned long long *bases(const BinLayout &b) { return kLevelA ? b.a_base : b.tile_base; }
-  __device__ static uint32_t stride(const BinLayout &b) { return kLevelA ? b.n_waves : b.count_stride; }
-  // keys of the whole pass and the row length of one key
-  __device__ static uint32_t total_keys(const BinLayout &b) { return kLevelA ? b.n_groups * kReplicas : b.n_tiles; }
-  __device__ static uint32_t row_length(const BinLayout &b, uint32_t key_global) {
-    if (kLevelA) return b.n_waves;
-    return b.two_level ? b.group_regions[key_global >> kGroupShift] : b.n_waves;
-  }
-  // the last group of a two-level layout may have fewer than kGroupTiles tiles
-  __device__ static uint32_t keys_of_region(const BinLayout &b, uint32_t k0) {
-    if (kLevelA || !b.two_level) return n_keys(b);
-    const uint32_t left = b.n_tiles - k0;
-    return left < kGroupTiles ? left : kGroupTiles;
-  }
-};
+__device__ __forceinline__ uint32_t wave_count_of(const BinLayout &b, uint32_t w) {
+  const uint32_t n = b.wave_count[w];  // written by the draw kernel; never beyond the segment
+  return n < b.cap ? n : b.cap;
+}
 
 // Exclusive prefix of v over the workgroup's threads (in thread order) and the workgroup total.
 // wave_totals: LDS scratch of blockDim/64 words; the caller separates two calls by a barrier.
@@ -137,60 +98,364 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
   return before + inc - v;
 }
 
-// The single-level region table: region r = wave r.
-__global__ void __launch_bounds__(256) bin_wave_regions_kernel(BinLayout b) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < b.n_waves) {
-    b.region_start[r] = (unsigned long long) r * b.cap;
-    b.region_count[r] = b.wave_count[r];
+// ---- region tables ---------------------------------------------------------------------------------
+
+// One level: wave w's segment [w * cap, w * cap + count) is cut into regions of kRegionEntries; all regions
+// belong to group 0.  One workgroup.
+__global__ void __launch_bounds__(1024) bin_wave_regions_kernel(BinLayout b) {
+  __shared__ uint32_t wave_totals[16];
+  const uint32_t per = (b.n_waves + 1023u) / 1024u;
+  const uint32_t w0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t w = w0 + k;
+    if (w < b.n_waves) mine += (wave_count_of(b, w) + kRegionEntries - 1u) / kRegionEntries;
   }
-  if (r == 0) *b.n_regions = b.n_waves;
+  uint32_t total = 0;
+  uint32_t r = block_exclusive_scan(mine, wave_totals, &total);
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t w = w0 + k;
+    if (w >= b.n_waves) break;
+    const uint32_t n = wave_count_of(b, w);
+    for (uint32_t s = 0; s < n; s += kRegionEntries, ++r) {
+      b.region_start[r] = (unsigned long long) w * b.cap + s;
+      b.region_count[r] = (n - s) < kRegionEntries ? (n - s) : kRegionEntries;
+      b.region_group[r] = 0u;
+    }
+  }
+  if (threadIdx.x == 0) {
+    *b.n_regions = total;
+    b.group_first[0] = 0u;
+    b.group_regions[0] = total;
+  }
 }
 
-template <bool kLevelA>
-__global__ void __launch_bounds__(kScatterThreads) bin_count_kernel(BinLayout b) {
-  using P = Pass<kLevelA>;
-  extern __shared__ uint32_t lds[];  // [n_keys]
+// Two levels: the region table from the group extents of `grouped` (a_base, scanned): group g's entries
+// are cut into regions of kGroupRegionEntries (a little short of kRegionEntries: these regions start anywhere,
+// and the sort reads from the 16-byte boundary below).  One workgroup, one thread per group.
+__global__ void __launch_bounds__(kMaxGroups) bin_group_regions_kernel(BinLayout b) {
+  __shared__ uint32_t wave_totals[kMaxGroups / 64];
+  const uint32_t g = threadIdx.x;
+  unsigned long long begin = 0, end = 0;
+  uint32_t mine = 0;
+  if (g < b.n_groups) {
+    begin = b.a_base[(size_t) g * kReplicas];
+    end = b.a_base[(size_t) (g + 1) * kReplicas];
+    mine = (uint32_t) ((end - begin + kGroupRegionEntries - 1u) / kGroupRegionEntries);
+  }
+  uint32_t total = 0;
+  const uint32_t first = block_exclusive_scan(mine, wave_totals, &total);
+  if (g == 0) *b.n_regions = total;
+  if (g < b.n_groups) {
+    b.group_first[g] = first;
+    b.group_regions[g] = mine;
+    for (uint32_t k = 0; k < mine; ++k) {
+      const uint32_t r = first + k;
+      const unsigned long long s = begin + (unsigned long long) k * kGroupRegionEntries;
+      b.region_start[r] = s;
+      b.region_count[r] = (uint32_t) ((end - s) < kGroupRegionEntries ? (end - s) : kGroupRegionEntries);
+      b.region_group[r] = g;
+    }
+  }
+}
+
+// slice_base[t] <- number of accumulate workgroups of tiles < t: tile t of group g takes
+// ceil(group_regions[g] / slice_regions) of them.  One workgroup.
+__global__ void __launch_bounds__(1024) bin_slice_table_kernel(BinLayout b) {
+  __shared__ uint32_t wave_totals[16];
+  const uint32_t nk = b.n_tiles;
+  const uint32_t per = (nk + 1023u) / 1024u;  // <= kMaxKeys / 1024
+  const uint32_t t0 = threadIdx.x * per;
+  auto slices_of = [&](uint32_t t) {
+    return (b.group_regions[t >> kGroupShift] + b.slice_regions - 1u) / b.slice_regions;
+  };
+  uint32_t mine = 0;
+  for (uint32_t k = 0; k < per; ++k) {
+    if (t0 + k < nk) mine += slices_of(t0 + k);
+  }
+  uint32_t total = 0;
+  uint32_t run = block_exclusive_scan(mine, wave_totals, &total);
+  for (uint32_t k = 0; k < per; ++k) {
+    const uint32_t t = t0 + k;
+    if (t < nk) {
+      b.slice_base[t] = run;
+      run += slices_of(t);
+    }
+  }
+  if (threadIdx.x == 0) b.slice_base[nk] = total;
+}
+
+// ---- region sort -----------------------------------------------------------------------------------
+//
+// LDS: cnt[1024 + 16] | wave_totals[16] | image[kRegionEntries + 16] (u16).  The image is kept congruent to
+// its place in `sorted` modulo 8 entries (16 bytes), so that it leaves with 16-byte stores wherever the region
+// starts (regions of a group start anywhere).  The per-entry steps are branch-free: the slots of a thread that
+// lie beyond the region count into cnt[1024] and are placed at image[kRegionEntries + 8], which nothing reads
+// (a branch per entry costs the compiler its scalar registers, and the kernel its second workgroup per CU).
+// The counters exist kCntReplicas times (a lane uses replica lane % kCntReplicas; a tile's run is the replicas'
+// stretches one after another): the stream is far from uniform over the tiles -- at C3 it spreads like 162
+// equally likely tiles, not 1024 -- and LDS atomics of one wave instruction on one address are served one
+// after another.
+constexpr uint32_t kDummyKey = kGroupTiles;
+constexpr uint32_t kDummyPlace = kRegionEntries + 8u;
+#ifndef CB_CNT_REPLICAS
+#define CB_CNT_REPLICAS 2
+#endif
+constexpr uint32_t kCntReplicas = CB_CNT_REPLICAS;
+constexpr uint32_t kCntStride = kGroupTiles + 16;
+constexpr size_t kSortLdsBytes =
+    (kCntReplicas * kCntStride + 16) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
+
+// kPlain: one plane and the plain word row << 16 | col (every render that is not a fused multi-channel one):
+// tile and offset with constant shifts instead of the layout's run-time fields.
+template <bool kPlain>
+__device__ __forceinline__ uint32_t sort_word(uint32_t e, uint32_t k0, const BinLayout &b) {
+  if (kPlain) {
+    const uint32_t key = __umul24(e >> (16 + kTileShift), b.tiles_x) + ((e & 0xffffu) >> kTileShift) - k0;
+    return (key << 16) | ((e >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) | (e & (kTileSize - 1u));
+  }
+  return ((tile_of(e, b) - k0) << 16) | offset_of(e, b);
+}
+
+template <bool kPlain>
+__global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b) {
+  extern __shared__ uint32_t lds[];
+  uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
+  uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
+  uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16);
+
   const uint32_t r = blockIdx.x;
-  if (r >= P::n_regions(b)) return;  // the grid is an upper bound (level B)
-  const uint32_t n = P::count_of(b, r);
-  const uint32_t *src = P::src(b, r);
-  const uint32_t k0 = P::key0(b, r), nk = P::keys_of_region(b, k0);
+  if (r >= *b.n_regions) return;  // the grid is an upper bound
+  const uint32_t n = b.region_count[r];
+  const unsigned long long start = b.region_start[r];
+  const uint32_t *src = (b.two_level ? b.grouped : b.stream) + start;
+  const uint32_t k0 = b.region_group[r] << kGroupShift;
+  const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
+  for (uint32_t t = threadIdx.x; t < kCntReplicas * kCntStride; t += kSortThreads) lds[t] = 0u;
+  __syncthreads();
+
+  // 1. the region's entries, once: e[k] = (key << 16) | in-tile offset, ~0 beyond the region; counts per tile.
+  // Which thread takes which entry does not matter: 16-byte loads from the 16-byte boundary below the region
+  // (a region of a group starts anywhere; `head` entries before it are masked, and regions that may start
+  // off a boundary are cut 8 entries short so that head + n still fits the 32 per thread).
+  uint32_t e[kSortPerThread];
+  {
+    const uint32_t head = (uint32_t) (start & 3ull);
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src - head);
+    const uint32_t lim = head + n;
+    const uint32_t last4 = lim ? (lim - 1u) >> 2 : 0u;  // loads are unconditional (index clamped): a load under a
+                                             // branch is issued and waited for alone
+    // two batches of four loads: eight in flight at once cost more registers than the second workgroup of
+    // a CU is worth
+#pragma unroll
+    for (uint32_t half = 0; half < 2; ++half) {
+      uint4 v[kSortPerThread / 8u];
+#pragma unroll
+      for (uint32_t j = 0; j < kSortPerThread / 8u; ++j) {
+        const uint32_t i4 = (half * (kSortPerThread / 8u) + j) * kSortThreads + threadIdx.x;
+        v[j] = src4[i4 < last4 ? i4 : last4];  // the last one may read up to three words past the region: inside the buffer
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < kSortPerThread / 8u; ++j) {
+        // the four words as they are, whatever the masks below say (else the compiler splits the load and
+        // hides its parts behind per-entry branches)
+        asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
+        const uint32_t k = half * (kSortPerThread / 8u) + j;
+        const uint32_t i = (k * kSortThreads + threadIdx.x) * 4u;
+        const uint32_t w0 = sort_word<kPlain>(v[j].x, k0, b), w1 = sort_word<kPlain>(v[j].y, k0, b);
+        const uint32_t w2 = sort_word<kPlain>(v[j].z, k0, b), w3 = sort_word<kPlain>(v[j].w, k0, b);
+        e[4 * k + 0] = (i >= head && i < lim) ? w0 : ~0u;
+        e[4 * k + 1] = (i + 1u >= head && i + 1u < lim) ? w1 : ~0u;
+        e[4 * k + 2] = (i + 2u >= head && i + 2u < lim) ? w2 : ~0u;
+        e[4 * k + 3] = (i + 3u < lim) ? w3 : ~0u;
+      }
+#pragma unroll
+      for (uint32_t k = half * (kSortPerThread / 2u); k < (half + 1u) * (kSortPerThread / 2u); ++k) {
+        const uint32_t key = e[k] >> 16;  // 0xffff beyond the region
+        lds_inc(&cnt[key < kDummyKey ? key : kDummyKey]);
+      }
+    }
+  }
+  __syncthreads();
+  // 2. where each tile's run starts: exclusive scan of the counts; published as run_start[tile][region]
+  {
+    uint32_t c[kCntReplicas], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kCntReplicas; ++k) {
+      c[k] = lds[k * kCntStride + threadIdx.x];
+      sum += c[k];
+    }
+    uint32_t total = 0;
+    uint32_t first = block_exclusive_scan(sum, wave_totals, &total);
+    __syncthreads();  // every count has been read
+    if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
+#pragma unroll
+    for (uint32_t k = 0; k < kCntReplicas; ++k) {
+      lds[k * kCntStride + threadIdx.x] = first;
+      first += c[k];
+    }
+  }
+  __syncthreads();
+  // 3. rank and place: the sorted image of the region, in LDS
+  const uint32_t shift = (uint32_t) (start & 7ull);
+#pragma unroll
+  for (uint32_t k = 0; k < kSortPerThread; ++k) {
+    const uint32_t key = e[k] >> 16;
+    const bool real = key < kDummyKey;
+    const uint32_t pos = __hip_atomic_fetch_add(&cnt[real ? key : kDummyKey], 1u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
+    image[real ? shift + pos : kDummyPlace] = (uint16_t) e[k];
+  }
+  __syncthreads();
+  // 4. the image leaves as one linear block: image[shift + i] -> sorted[start + i]
+  uint16_t *dst = b.sorted + (start - shift);  // 16-byte aligned; index = position in the image
+  const uint32_t lo = shift, hi = shift + n;
+  const uint32_t body_lo = (lo + 7u) & ~7u, body_hi = hi & ~7u;
+  if (body_lo < body_hi) {
+    for (uint32_t i = lo + threadIdx.x; i < body_lo; i += kSortThreads) dst[i] = image[i];
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(image);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    for (uint32_t i = (body_lo >> 3) + threadIdx.x; i < (body_hi >> 3); i += kSortThreads) d4[i] = s4[i];
+    for (uint32_t i = body_hi + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
+  } else {
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
+  }
+}
+
+// ---- gather + accumulate ---------------------------------------------------------------------------
+
+// One workgroup per (tile, slice of regions).  (Measured too: one workgroup of 1024 threads per PAIR of tiles,
+// whose runs lie side by side -- a third fewer 128-byte lines fetched, half the workgroups per CU: no faster.)
+__global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinLayout b,
+                                                                            unsigned long long *hist,
+                                                                            int w, int h) {
+  __shared__ uint32_t tile[kTilePixels];  // 64 KiB
+  // which (tile, slice) is this workgroup?  slice_base is an exclusive prefix: binary search
+  const uint32_t s = blockIdx.x;
+  if (s >= b.slice_base[b.n_tiles]) return;  // the grid is an upper bound
+  uint32_t lo = 0, hi = b.n_tiles;  // invariant: slice_base[lo] <= s < slice_base[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (b.slice_base[mid] <= s) {
+      lo = mid;
+    } else {
+      hi = mid;
+    }
+  }
+  const uint32_t t = lo;
+  const uint32_t g = t >> kGroupShift, kl = t & (kGroupTiles - 1u);
+  const uint32_t k0 = g << kGroupShift;
+  const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
+  const uint32_t first = b.group_first[g], n_reg = b.group_regions[g];
+  const uint32_t r0 = (s - b.slice_base[t]) * b.slice_regions;
+  const uint32_t r1 = (r0 + b.slice_regions < n_reg) ? r0 + b.slice_regions : n_reg;
+
+  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) tile[p] = 0u;
+  __syncthreads();
+  // Each lane walks one region's run of this tile: [beg, end) inside the region's sorted image, read with
+  // 16-byte loads from the 16-byte boundary below the run (entries outside the run are masked).
+  const uint16_t *row0 = b.run_start + (size_t) kl * b.max_regions + first;
+  const bool last_key = (kl + 1u == nk);  // its runs end where the region ends
+  const uint16_t *row1 = row0 + b.max_regions;
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  for (uint32_t base = r0 + wv * 64u; base < r1; base += (kAccThreads / 64u) * 64u) {
+    const uint32_t rr = base + lane;
+    // positions relative to the 16-byte boundary below the run: the run is [lead, len) of what is read
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(b.sorted);  // lanes without a run load (and ignore) its first bytes
+    uint32_t lead = 0, len = 0;
+    if (rr < r1) {
+      const unsigned long long rs = b.region_start[first + rr];
+      const unsigned long long beg = rs + row0[rr];
+      const unsigned long long end = rs + (last_key ? b.region_count[first + rr] : (uint32_t) row1[rr]);
+      lead = (uint32_t) (beg & 7ull);
+      len = lead + (uint32_t) (end - beg);
+      if (len == lead) {
+        len = lead = 0u;  // an empty run reads nothing
+      } else {
+        p4 = reinterpret_cast<const uint4 *>(b.sorted + (beg - lead));
+      }
+    }
+    const uint32_t last8 = len ? (len - 1u) >> 3 : 0u;  // loads are unconditional, the index clamped to the run
+    for (uint32_t at = 0; __ballot(at < len) != 0ull; at += 32u) {
+      if (at < len) {
+        // up to 32 entries = four 16-byte loads in flight per lane
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t i8 = (at >> 3) + j;
+          v[j] = p4[i8 < last8 ? i8 : last8];
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+          const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t i = at + 8u * j + q;
+            if (i >= lead && i < len) lds_inc(&tile[(words[q >> 1] >> ((q & 1u) * 16u)) & 0xffffu]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t plane_tiles = b.tiles_x * b.tiles_y;
+  const uint32_t plane = t / plane_tiles, tt = t - plane * plane_tiles;
+  const uint32_t row_0 = (tt / b.tiles_x) << kTileShift;
+  const uint32_t col_0 = (tt % b.tiles_x) << kTileShift;
+  hist += (unsigned long long) plane * b.plane_pixels;
+  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) {
+    const uint32_t v = tile[p];
+    if (v != 0u) {
+      const uint32_t row = row_0 + (p >> kTileShift);
+      const uint32_t col = col_0 + (p & (kTileSize - 1u));
+      if (row < (uint32_t) h && col < (uint32_t) w) {  // always true for a recorded pixel
+        __hip_atomic_fetch_add(hist + ((unsigned long long) row * (unsigned long long) w + col),
+                               (unsigned long long) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+// ---- level A (two levels only): the stream, partitioned into groups of 1024 tiles -------------------
+//
+// A counting sort over the wave segments: count[key][wave] (LDS histogram per wave segment) -> exclusive
+// prefix over waves per key, then over keys -> scatter of whole words into `grouped`, chunk by chunk
+// through LDS so that consecutive lanes write consecutive places of a run.  key = group * kReplicas + a
+// replica that is a function of the entry's index alone (the count and the scatter kernel evaluate it with
+// different thread mappings).
+__device__ __forceinline__ uint32_t group_key(const BinLayout &b, uint32_t e, uint32_t j) {
+  return ((tile_of(e, b) >> kGroupShift) * kReplicas) | (j & (kReplicas - 1u));
+}
+
+__global__ void __launch_bounds__(kScatterThreads) group_count_kernel(BinLayout b) {
+  extern __shared__ uint32_t lds[];  // [n_groups * kReplicas]
+  const uint32_t r = blockIdx.x;
+  const uint32_t n = wave_count_of(b, r);
+  const uint32_t *src = b.stream + (size_t) r * b.cap;  // 16-byte aligned: cap is a multiple of 8
+  const uint32_t nk = b.n_groups * kReplicas;
   for (uint32_t t = threadIdx.x; t < nk; t += blockDim.x) lds[t] = 0u;
   __syncthreads();
-  // entries up to a 16-byte boundary, then four per load, then the tail (level-B regions start anywhere)
-  uint32_t head = (4u - (uint32_t) ((reinterpret_cast<uintptr_t>(src) >> 2) & 3u)) & 3u;
-  if (head > n) head = n;
-  if (threadIdx.x < head) lds_inc(&lds[P::key(b, src[threadIdx.x], k0, threadIdx.x)]);
-  const uint32_t n4 = (n - head) >> 2;
-  const uint4 *src4 = reinterpret_cast<const uint4 *>(src + head);
+  const uint32_t n4 = n >> 2;
+  const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
   for (uint32_t i = threadIdx.x; i < n4; i += blockDim.x) {
     const uint4 v = src4[i];
-    const uint32_t j = head + (i << 2);
-    lds_inc(&lds[P::key(b, v.x, k0, j)]);
-    lds_inc(&lds[P::key(b, v.y, k0, j + 1u)]);
-    lds_inc(&lds[P::key(b, v.z, k0, j + 2u)]);
-    lds_inc(&lds[P::key(b, v.w, k0, j + 3u)]);
+    const uint32_t j = i << 2;
+    lds_inc(&lds[group_key(b, v.x, j)]);
+    lds_inc(&lds[group_key(b, v.y, j + 1u)]);
+    lds_inc(&lds[group_key(b, v.z, j + 2u)]);
+    lds_inc(&lds[group_key(b, v.w, j + 3u)]);
   }
-  for (uint32_t i = head + (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) {
-    lds_inc(&lds[P::key(b, src[i], k0, i)]);
-  }
+  for (uint32_t i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) lds_inc(&lds[group_key(b, src[i], i)]);
   __syncthreads();
-  // key-major: the scan over regions reads each key's row contiguously
-  uint32_t *out = P::counts(b);
-  const uint32_t col = P::column(b, r), stride = P::stride(b);
-  for (uint32_t t = threadIdx.x; t < nk; t += blockDim.x) {
-    out[(size_t) (k0 + t) * stride + col] = lds[t];
-  }
+  // key-major: the scan over waves reads each key's row contiguously
+  for (uint32_t t = threadIdx.x; t < nk; t += blockDim.x) b.a_count[(size_t) t * b.n_waves + r] = lds[t];
 }
 
-// counts[key][c] <- sum of counts[key][c'] for c' < c; bases[key] <- total of the key (scanned next).
-template <bool kLevelA>
-__global__ void __launch_bounds__(256) bin_scan_rows_kernel(BinLayout b) {
-  using P = Pass<kLevelA>;
+// a_count[key][w] <- sum of a_count[key][w'] for w' < w; a_base[key] <- total of the key (scanned next).
+__global__ void __launch_bounds__(256) group_scan_rows_kernel(BinLayout b) {
   __shared__ uint32_t wave_totals[4];
-  const uint32_t len = P::row_length(b, blockIdx.x);
-  uint32_t *row = P::counts(b) + (size_t) blockIdx.x * P::stride(b);
+  const uint32_t len = b.n_waves;
+  uint32_t *row = b.a_count + (size_t) blockIdx.x * b.n_waves;
   const uint32_t per = (len + blockDim.x - 1u) / blockDim.x;
   const uint32_t w0 = threadIdx.x * per;
   uint32_t sum = 0;
@@ -206,30 +471,15 @@ __global__ void __launch_bounds__(256) bin_scan_rows_kernel(BinLayout b) {
       run += c;
     }
   }
-  if (threadIdx.x == 0) P::bases(b)[blockIdx.x] = total;
+  if (threadIdx.x == 0) b.a_base[blockIdx.x] = total;
 }
 
-// bases[key] <- sum of totals of keys < key (bases[n] <- grand total); for tiles also
-// slice_base[t] <- number of accumulate slices of tiles < t.  One workgroup.
-constexpr uint32_t kMaxKeys = kMaxGroups * kGroupTiles;
-template <bool kLevelA>
-__global__ void __launch_bounds__(1024) bin_scan_keys_kernel(BinLayout b) {
-  using P = Pass<kLevelA>;
+// a_base[key] <- sum of totals of keys < key (a_base[n] <- grand total).  One workgroup.
+__global__ void __launch_bounds__(1024) group_scan_keys_kernel(BinLayout b) {
   __shared__ unsigned long long part[1024];
-  __shared__ uint32_t wave_totals[16];
-  unsigned long long *base = P::bases(b);
-  const uint32_t nk = P::total_keys(b);
-  const uint32_t per = (nk + 1023u) / 1024u;  // keys per thread, <= kMaxKeys / 1024
-  const uint32_t t0 = threadIdx.x * per;
-  unsigned long long sum = 0;
-  uint32_t slices = 0;
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t t = t0 + k;
-    const unsigned long long v = t < nk ? base[t] : 0ull;
-    sum += v;
-    slices += (uint32_t) ((v + b.slice_entries - 1u) / b.slice_entries);
-  }
-  part[threadIdx.x] = sum;
+  const uint32_t nk = b.n_groups * kReplicas;  // <= 1024
+  const unsigned long long v = threadIdx.x < nk ? b.a_base[threadIdx.x] : 0ull;
+  part[threadIdx.x] = v;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan (64-bit)
     const unsigned long long add = threadIdx.x >= d ? part[threadIdx.x - d] : 0ull;
@@ -237,81 +487,27 @@ __global__ void __launch_bounds__(1024) bin_scan_keys_kernel(BinLayout b) {
     part[threadIdx.x] += add;
     __syncthreads();
   }
-  uint32_t slice_total = 0;
-  uint32_t srun = block_exclusive_scan(slices, wave_totals, &slice_total);
-  unsigned long long run = part[threadIdx.x] - sum;
-  for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t t = t0 + k;
-    if (t < nk) {
-      const unsigned long long v = base[t];
-      base[t] = run;
-      if (!kLevelA) b.slice_base[t] = srun;
-      run += v;
-      srun += (uint32_t) ((v + b.slice_entries - 1u) / b.slice_entries);
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 1023) {
-    base[nk] = part[1023];
-    if (!kLevelA) b.slice_base[nk] = slice_total;
-  }
+  if (threadIdx.x < nk) b.a_base[threadIdx.x] = part[threadIdx.x] - v;
+  if (threadIdx.x == 1023) b.a_base[nk] = part[1023];
 }
 
-// Level-B region table from the group extents of `grouped` (a_base, scanned): group g's entries are
-// cut into regions of kRegionEntries.  One workgroup, one thread per group.
-__global__ void __launch_bounds__(kMaxGroups) bin_group_regions_kernel(BinLayout b) {
-  __shared__ uint32_t first[kMaxGroups + 1];
-  __shared__ uint32_t wave_totals[kMaxGroups / 64];
-  const uint32_t g = threadIdx.x;
-  unsigned long long begin = 0, end = 0;
-  uint32_t mine = 0;
-  if (g < b.n_groups) {
-    begin = b.a_base[(size_t) g * kReplicas];
-    end = b.a_base[(size_t) (g + 1) * kReplicas];
-    mine = (uint32_t) ((end - begin + kRegionEntries - 1u) / kRegionEntries);
-    b.group_regions[g] = mine;
-  }
-  uint32_t total = 0;
-  first[g] = block_exclusive_scan(mine, wave_totals, &total);
-  __syncthreads();
-  if (g == 0) *b.n_regions = total;
-  if (g < b.n_groups) {
-    for (uint32_t k = 0; k < mine; ++k) {
-      const uint32_t r = first[g] + k;
-      const unsigned long long s = begin + (unsigned long long) k * kRegionEntries;
-      b.region_start[r] = s;
-      b.region_count[r] = (uint32_t) ((end - s) < kRegionEntries ? (end - s) : kRegionEntries);
-      b.region_group[r] = g;
-      b.region_index[r] = k;
-    }
-  }
-}
-
-template <bool kLevelA>
-__global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout b) {
-  using P = Pass<kLevelA>;
+__global__ void __launch_bounds__(kScatterThreads) group_scatter_kernel(BinLayout b) {
   extern __shared__ uint32_t lds[];
   // dynamic LDS: bounds[nk] {start of the key's run in the sorted chunk, its next place in the output} |
-  // cnt[nk] | wave_totals[8] | sorted[chunk] {place in the output, payload}.  Pairs, so that sorting an
-  // entry is one 8-byte read and one 8-byte write and copying it out one 8-byte read.
-  const uint32_t nk_lds = P::n_keys(b);
+  // cnt[nk] | wave_totals[8] | sorted[chunk] {place in the output, word}
+  const uint32_t nk = b.n_groups * kReplicas;
   uint2 *bounds = reinterpret_cast<uint2 *>(lds);
-  uint32_t *cnt = lds + 2u * nk_lds;
-  uint32_t *wave_totals = cnt + nk_lds;
+  uint32_t *cnt = lds + 2u * nk;
+  uint32_t *wave_totals = cnt + nk;
   uint2 *sorted = reinterpret_cast<uint2 *>(wave_totals + 8);
 
   const uint32_t r = blockIdx.x;
-  if (r >= P::n_regions(b)) return;
-  const uint32_t n = P::count_of(b, r);
+  const uint32_t n = wave_count_of(b, r);
   if (n == 0) return;
-  const uint32_t *src = P::src(b, r);
-  const uint32_t k0 = P::key0(b, r), nk = P::keys_of_region(b, k0);
-  const uint32_t col = P::column(b, r), stride = P::stride(b);
-  const uint32_t *counts = P::counts(b);
-  const unsigned long long *bases = P::bases(b);
+  const uint32_t *src = b.stream + (size_t) r * b.cap;
   for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) {
     // all entries together are < 2^32, so 32-bit places suffice
-    bounds[t].y = (uint32_t) bases[k0 + t] + counts[(size_t) (k0 + t) * stride + col];
+    bounds[t].y = (uint32_t) b.a_base[t] + b.a_count[(size_t) t * b.n_waves + r];
   }
   const uint32_t bins_per_thread = (nk + kScatterThreads - 1u) / kScatterThreads;
 
@@ -333,7 +529,7 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
       rank[k] = 0u;
       key[k] = ~0u;  // beyond the chunk
       if (i < m) {
-        key[k] = P::key(b, e[k], k0, base + i);
+        key[k] = group_key(b, e[k], base + i);
         rank[k] = __hip_atomic_fetch_add(&cnt[key[k]], 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
       }
@@ -357,92 +553,22 @@ __global__ void __launch_bounds__(kScatterThreads) bin_scatter_kernel(BinLayout 
       taken_in_chunk = total;
     }
     __syncthreads();
-    // 3. sort the chunk in LDS: destination place and payload, key by key
+    // 3. sort the chunk in LDS: destination place and word, key by key
 #pragma unroll
     for (uint32_t k = 0; k < kPerThread; ++k) {
       if (key[k] != ~0u) {
         const uint2 bd = bounds[key[k]];
-        sorted[bd.x + rank[k]] = make_uint2(bd.y + rank[k], kLevelA ? e[k] : offset_of(e[k], b));
+        sorted[bd.x + rank[k]] = make_uint2(bd.y + rank[k], e[k]);
       }
     }
     __syncthreads();
     // 4. write the runs out (consecutive lanes -> consecutive places of a run) and advance the places
-    if (kLevelA) {
-      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) {
-        const uint2 v = sorted[i];
-        b.grouped[v.x] = v.y;
-      }
-    } else {
-      for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) {
-        const uint2 v = sorted[i];
-        b.sorted[v.x] = (uint16_t) v.y;
-      }
+    for (uint32_t i = threadIdx.x; i < taken_in_chunk; i += kScatterThreads) {
+      const uint2 v = sorted[i];
+      b.grouped[v.x] = v.y;
     }
     for (uint32_t t = threadIdx.x; t < nk; t += kScatterThreads) bounds[t].y += cnt[t];
     __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(kAccThreads) bin_accumulate_kernel(BinLayout b,
-                                                                     unsigned long long *hist,
-                                                                     int w, int h) {
-  __shared__ uint32_t tile[kTilePixels];  // 64 KiB
-  // which (tile, slice) is this workgroup?  slice_base is an exclusive prefix: binary search
-  const uint32_t s = blockIdx.x;
-  if (s >= b.slice_base[b.n_tiles]) return;  // the grid is an upper bound
-  uint32_t lo = 0, hi = b.n_tiles;  // invariant: slice_base[lo] <= s < slice_base[hi]
-  while (hi - lo > 1u) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (b.slice_base[mid] <= s) {
-      lo = mid;
-    } else {
-      hi = mid;
-    }
-  }
-  const uint32_t t = lo;
-  const unsigned long long tile_begin = b.tile_base[t], tile_end = b.tile_base[t + 1];
-  const unsigned long long begin = tile_begin + (unsigned long long) (s - b.slice_base[t]) * b.slice_entries;
-  const unsigned long long end = (begin + b.slice_entries < tile_end) ? begin + b.slice_entries : tile_end;
-
-  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) tile[p] = 0u;
-  __syncthreads();
-  // head up to a 16-byte boundary, then 8 entries per load, then the tail
-  const uint16_t *src = b.sorted;
-  unsigned long long body = (begin + 7ull) & ~7ull;
-  if (body > end) body = end;
-  for (unsigned long long i = begin + threadIdx.x; i < body; i += kAccThreads) lds_inc(&tile[src[i]]);
-  const unsigned long long n8 = (end - body) >> 3;
-  const uint4 *src8 = reinterpret_cast<const uint4 *>(src + body);
-  for (unsigned long long i = threadIdx.x; i < n8; i += kAccThreads) {
-    const uint4 v = src8[i];
-    lds_inc(&tile[v.x & 0xffffu]);
-    lds_inc(&tile[v.x >> 16]);
-    lds_inc(&tile[v.y & 0xffffu]);
-    lds_inc(&tile[v.y >> 16]);
-    lds_inc(&tile[v.z & 0xffffu]);
-    lds_inc(&tile[v.z >> 16]);
-    lds_inc(&tile[v.w & 0xffffu]);
-    lds_inc(&tile[v.w >> 16]);
-  }
-  for (unsigned long long i = body + (n8 << 3) + threadIdx.x; i < end; i += kAccThreads) {
-    lds_inc(&tile[src[i]]);
-  }
-  __syncthreads();
-  const uint32_t plane_tiles = b.tiles_x * b.tiles_y;
-  const uint32_t plane = t / plane_tiles, tt = t - plane * plane_tiles;
-  const uint32_t row0 = (tt / b.tiles_x) << kTileShift;
-  const uint32_t col0 = (tt % b.tiles_x) << kTileShift;
-  hist += (unsigned long long) plane * b.plane_pixels;
-  for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) {
-    const uint32_t v = tile[p];
-    if (v != 0u) {
-      const uint32_t row = row0 + (p >> kTileShift);
-      const uint32_t col = col0 + (p & (kTileSize - 1u));
-      if (row < (uint32_t) h && col < (uint32_t) w) {  // always true for a recorded pixel
-        __hip_atomic_fetch_add(hist + ((unsigned long long) row * (unsigned long long) w + col),
-                               (unsigned long long) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
   }
 }
 
@@ -464,30 +590,31 @@ Shape shape_of(int w, int h, uint32_t planes) {
   s.tiles_x = tiles_x;
   s.tiles_y = tiles_y;
   s.n_tiles = (uint32_t) n;
-  s.two_level = n > kMaxTiles ? 1u : 0u;
+  s.two_level = n > kGroupTiles ? 1u : 0u;
   if (const char *e = getenv("CUDABROT_AMD_TWO_LEVEL")) {  // test knob: two levels on a small canvas
     if (atoi(e) != 0) s.two_level = 1u;
   }
-  s.n_groups = s.two_level ? (s.n_tiles + kGroupTiles - 1u) / kGroupTiles : 0u;
+  s.n_groups = (s.n_tiles + kGroupTiles - 1u) / kGroupTiles;
   return s;
 }
 
-// Upper bound on the number of level-B regions for `entries` stream entries.
+// Upper bound on the number of regions for `entries` stream entries: every wave segment (one level) or
+// group (two levels) ends with one partial region.
 uint32_t max_regions_for(const Shape &s, uint32_t n_waves, unsigned long long entries) {
-  if (!s.two_level) return n_waves;
-  return (uint32_t) (entries / kRegionEntries) + s.n_groups + 1u;
+  if (s.two_level) return (uint32_t) (entries / kGroupRegionEntries) + s.n_groups + 1u;
+  return (uint32_t) (entries / kRegionEntries) + n_waves + 1u;
 }
 
 // Bytes of everything but the per-entry buffers, for a region table of max_regions.
 size_t fixed_bytes(const Shape &s, uint32_t n_waves, uint32_t max_regions) {
+  const size_t rows = s.n_tiles < kGroupTiles ? s.n_tiles : kGroupTiles;
   size_t b = 0;
   b += round_up((size_t) n_waves * sizeof(uint32_t), 256);                          // wave_count
   b += round_up((size_t) max_regions * sizeof(unsigned long long), 256);            // region_start
-  b += 3 * round_up((size_t) max_regions * sizeof(uint32_t), 256);                  // region_count/group/index
-  b += round_up((size_t) (kMaxGroups + 1) * sizeof(uint32_t), 256);                 // group_regions
+  b += 2 * round_up((size_t) max_regions * sizeof(uint32_t), 256);                  // region_count/group
+  b += 2 * round_up((size_t) kMaxGroups * sizeof(uint32_t), 256);                  // group_first/regions
   b += 256;                                                                         // n_regions
-  b += round_up((size_t) s.n_tiles * max_regions * sizeof(uint32_t), 256);          // count
-  b += round_up(((size_t) s.n_tiles + 1) * sizeof(unsigned long long), 256);        // tile_base
+  b += round_up(rows * max_regions * sizeof(uint16_t), 256);                        // run_start
   b += round_up(((size_t) s.n_tiles + 1) * sizeof(uint32_t), 256);                  // slice_base
   if (s.two_level) {
     const size_t keys = (size_t) s.n_groups * kReplicas;
@@ -506,6 +633,14 @@ T *carve(uintptr_t &p, size_t bytes) {
   T *r = reinterpret_cast<T *>(p);
   p += round_up(bytes, 256);
   return r;
+}
+
+uint32_t slice_regions_setting() {
+  if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob: regions per accumulate workgroup
+    const long v = atol(e);
+    if (v >= 1 && v <= (1l << 24)) return (uint32_t) v;
+  }
+  return kSliceRegionsDefault;
 }
 
 }  // namespace
@@ -541,11 +676,7 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
     b.e_col_mask = (1u << cb_) - 1u;
     b.e_row_mask = (1u << rb) - 1u;
   }
-  b.slice_entries = kSliceEntriesDefault;
-  if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob
-    const long v = atol(e);
-    if (v >= 4096 && v <= (1l << 30)) b.slice_entries = (uint32_t) v;
-  }
+  b.slice_regions = slice_regions_setting();
   b.n_waves = n_waves;
   const Shape s = shape_of(w, h, b.n_planes);
   if (!workspace || n_waves == 0 || !s.ok) return b;
@@ -559,35 +690,34 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   const uintptr_t p_end = p + bytes;
   p = (p + 255) & ~(uintptr_t) 255;
   if (p >= p_end) return b;
-  // The region table (and with it the count matrix) is sized by the entries, which are sized by what
-  // is left: shrink cap until everything fits.
+  // The region table (and with it run_start) is sized by the entries, which are sized by what is left:
+  // shrink cap until everything fits.
   const size_t per_entry = bytes_per_entry(s);
   unsigned long long cap = (p_end - p) / (per_entry * (size_t) n_waves);
   const unsigned long long cap_limit = 0xffffffffull / n_waves;  // all entries together < 2^32
   if (cap > cap_limit) cap = cap_limit;
   for (;;) {
-    cap &= ~3ull;
+    cap &= ~7ull;  // segments start on 16-byte boundaries of the 16-bit sorted image too
     if (cap < kMinRegionEntries) return b;
     const uint32_t mr = max_regions_for(s, n_waves, cap * n_waves);
     const size_t need = fixed_bytes(s, n_waves, mr) + (size_t) cap * n_waves * per_entry + 1024;
     if (p + need <= p_end) break;
     const size_t over = p + need - p_end;
-    const unsigned long long cut = over / (per_entry * (size_t) n_waves) + 4;
+    const unsigned long long cut = over / (per_entry * (size_t) n_waves) + 8;
     if (cut >= cap) return b;
     cap -= cut;
   }
   b.cap = (uint32_t) cap;
   b.max_regions = max_regions_for(s, n_waves, cap * n_waves);
-  b.count_stride = b.max_regions;
+  const size_t rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
   b.wave_count = carve<uint32_t>(p, (size_t) n_waves * sizeof(uint32_t));
   b.region_start = carve<unsigned long long>(p, (size_t) b.max_regions * sizeof(unsigned long long));
   b.region_count = carve<uint32_t>(p, (size_t) b.max_regions * sizeof(uint32_t));
   b.region_group = carve<uint32_t>(p, (size_t) b.max_regions * sizeof(uint32_t));
-  b.region_index = carve<uint32_t>(p, (size_t) b.max_regions * sizeof(uint32_t));
-  b.group_regions = carve<uint32_t>(p, (size_t) (kMaxGroups + 1) * sizeof(uint32_t));
+  b.group_first = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
+  b.group_regions = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
   b.n_regions = carve<uint32_t>(p, 256);
-  b.count = carve<uint32_t>(p, (size_t) b.n_tiles * b.max_regions * sizeof(uint32_t));
-  b.tile_base = carve<unsigned long long>(p, ((size_t) b.n_tiles + 1) * sizeof(unsigned long long));
+  b.run_start = carve<uint16_t>(p, rows * b.max_regions * sizeof(uint16_t));
   b.slice_base = carve<uint32_t>(p, ((size_t) b.n_tiles + 1) * sizeof(uint32_t));
   if (b.two_level) {
     const size_t keys = (size_t) b.n_groups * kReplicas;
@@ -601,47 +731,47 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   return b;
 }
 
-namespace {
-
-template <bool kLevelA>
-hipError_t launch_pass(const BinLayout &b, uint32_t n_keys_lds, uint32_t total_keys, uint32_t regions,
-                       hipStream_t stream) {
-  const size_t count_lds = (size_t) n_keys_lds * sizeof(uint32_t);
-  hipLaunchKernelGGL((bin_count_kernel<kLevelA>), dim3(regions), dim3(kScatterThreads), count_lds, stream, b);
-  hipLaunchKernelGGL((bin_scan_rows_kernel<kLevelA>), dim3(total_keys), dim3(256), 0, stream, b);
-  hipLaunchKernelGGL((bin_scan_keys_kernel<kLevelA>), dim3(1), dim3(1024), 0, stream, b);
-  if (kLevelA) hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(kMaxGroups), 0, stream, b);
-  const size_t scatter_lds = ((size_t) 3 * n_keys_lds + 8 + 2 * kChunkEntries) * sizeof(uint32_t);
-  if (scatter_lds > 64 * 1024) {  // 76 KiB at 1024 keys, 112 KiB at 4096 tiles; gfx950 has 160 KiB per workgroup
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_scatter_kernel<kLevelA>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) scatter_lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((bin_scatter_kernel<kLevelA>), dim3(regions), dim3(kScatterThreads), scatter_lds, stream, b);
-  return hipGetLastError();
-}
-
-}  // namespace
-
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream) {
   if (!b.enabled) return hipSuccess;
-  hipError_t e;
-  if (b.two_level) {
-    // level-B rows of the count matrix are group_regions[g] long; columns beyond a group's regions are
-    // neither written nor read
-    e = launch_pass<true>(b, b.n_groups * kReplicas, b.n_groups * kReplicas, b.n_waves, stream);
+  {  // per call: the attribute belongs to the current device
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_region_sort_kernel<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) kSortLdsBytes);  // 68 KiB of the 160 per CU
+    if (e == hipSuccess) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_region_sort_kernel<false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSortLdsBytes);
+    }
     if (e != hipSuccess) return e;
-    e = launch_pass<false>(b, kGroupTiles, b.n_tiles, b.max_regions, stream);
-  } else {
-    hipLaunchKernelGGL(bin_wave_regions_kernel, dim3((b.n_waves + 255u) / 256u), dim3(256), 0, stream, b);
-    e = launch_pass<false>(b, b.n_tiles, b.n_tiles, b.n_waves, stream);
   }
-  if (e != hipSuccess) return e;
-  // upper bound on the number of slices: one partial slice per tile + the full ones
-  const unsigned long long max_entries = (unsigned long long) b.n_waves * b.cap;
-  const uint32_t slices = b.n_tiles + (uint32_t) (max_entries / b.slice_entries) + 1u;
-  hipLaunchKernelGGL(bin_accumulate_kernel, dim3(slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
+  if (b.two_level) {
+    const uint32_t nk = b.n_groups * kReplicas;
+    hipLaunchKernelGGL(group_count_kernel, dim3(b.n_waves), dim3(kScatterThreads), nk * sizeof(uint32_t), stream, b);
+    hipLaunchKernelGGL(group_scan_rows_kernel, dim3(nk), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(group_scan_keys_kernel, dim3(1), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(kMaxGroups), 0, stream, b);
+    const size_t scatter_lds = ((size_t) 3 * nk + 8 + 2 * kChunkEntries) * sizeof(uint32_t);
+    if (scatter_lds > 64 * 1024) {  // 76 KiB at 1024 keys; gfx950 has 160 KiB per workgroup
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(group_scatter_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) scatter_lds);
+      if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(b.n_waves), dim3(kScatterThreads), scatter_lds, stream, b);
+  } else {
+    hipLaunchKernelGGL(bin_wave_regions_kernel, dim3(1), dim3(1024), 0, stream, b);
+  }
+  hipLaunchKernelGGL(bin_slice_table_kernel, dim3(1), dim3(1024), 0, stream, b);
+  const bool plain = b.n_planes == 1u && b.e_row_shift == 16u && b.e_col_mask == 0xffffu && b.e_row_mask == 0xffffu &&
+                     b.e_chan_mask == 0u;
+  if (plain) {
+    hipLaunchKernelGGL(bin_region_sort_kernel<true>, dim3(b.max_regions), dim3(kSortThreads), kSortLdsBytes, stream, b);
+  } else {
+    hipLaunchKernelGGL(bin_region_sort_kernel<false>, dim3(b.max_regions), dim3(kSortThreads), kSortLdsBytes, stream, b);
+  }
+  // upper bound on the accumulate workgroups: every tile's last, partial slice + the full ones
+  const unsigned long long rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
+  const unsigned long long slices = b.n_tiles + rows * b.max_regions / b.slice_regions + 1ull;
+  hipLaunchKernelGGL(bin_gather_accumulate_kernel, dim3((uint32_t) slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
   return hipGetLastError();
 }
 

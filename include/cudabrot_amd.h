@@ -117,12 +117,14 @@ size_t cb_rng_state_bytes(uint32_t n_threads);
 int cb_initialize_rng(uint64_t seed, uint64_t first_subsequence, uint32_t n_threads, void *d_states,
                       void *stream);
 
-/* Suggested size of the scatter workspace of cb_draw_buddhabrot (and cb_draw_buddhabrot_channels) for
- * launches of this shape (0 if the canvas cannot use one: more than 262144 tiles of 128x128 pixels, or a
- * side above 65536).  Any size works: increments that do not fit are added with direct atomics, the
- * result is the same. */
+/* Suggested size of the scatter workspace of cb_draw_buddhabrot for launches of this shape (0 if the canvas
+ * cannot use one: more than 262144 tiles of 128x128 pixels, or a side above 65536).  Any size works:
+ * increments that do not fit are added with direct atomics, the result is the same. */
 size_t cb_scatter_workspace_bytes(const cb_fractal_dimensions *dims, uint32_t n_threads,
                                   uint32_t samples_per_thread);
+/* ... of cb_draw_buddhabrot_channels with n_channels planes (their tiles are sorted as one canvas). */
+size_t cb_scatter_workspace_bytes_channels(const cb_fractal_dimensions *dims, int n_channels, uint32_t n_threads,
+                                           uint32_t samples_per_thread);
 
 /* DrawBuddhabrot<<<block_count, block_size>>>(dimensions, data, iterations, states)
  * (cudabrot.cu:379-414,485-486) for n_threads threads, samples_per_thread samples each (the
@@ -168,7 +170,7 @@ int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32
  * then sorted and accumulated together, as one taller canvas.  d_hist is
  * n_channels planes of w*h counters, plane j = what cb_draw_buddhabrot would add with windows[j].
  * The wave-scheduled kernel only (variant flags as above); cb_flush_scatter_channels after each
- * launch that was given a workspace (sized by cb_scatter_workspace_bytes).
+ * launch that was given a workspace (sized by cb_scatter_workspace_bytes_channels).
  * Counters of a fused launch: samples, rejected, never_escaped (against the largest max) and
  * iterate_steps as for one run with the largest max; too_fast = orbits that escaped but whose index
  * lies in no window; recorded = orbits in at least one window; replay_steps counts every replay (a first,

@@ -19,7 +19,7 @@ def _fused(cb, w, h, windows, t, passes, mode, box=BOX, per_launch=1):
     hist = torch.zeros(k * h * w, dtype=torch.int64, device=dev)
     counters = torch.zeros(17, dtype=torch.int64, device=dev)
     spt = 50 * per_launch
-    ws_bytes = cb.scatter_workspace_bytes(dims, t, spt * 4) if mode != "atomics" else 0
+    ws_bytes = cb.scatter_workspace_bytes(dims, t, spt * 4, n_channels=len(windows)) if mode != "atomics" else 0
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     carry = torch.zeros(cb.carry_bytes(t), dtype=torch.uint8, device=dev) if mode == "carry" else None
     stream = torch.cuda.current_stream().cuda_stream
@@ -135,7 +135,7 @@ def test_four_planes_of_the_recipe_canvas_are_more_than_65536_tiles(cb):
 
     planes = torch.zeros(len(windows) * w * h, dtype=torch.int64, device=dev)
     counters = torch.zeros(17, dtype=torch.int64, device=dev)
-    ws_bytes = cb.scatter_workspace_bytes(dims, t, spt)
+    ws_bytes = cb.scatter_workspace_bytes(dims, t, spt, n_channels=len(windows))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = states()
     cb.draw_buddhabrot_channels(dims, planes.data_ptr(), windows, st.data_ptr(), t, spt, counters.data_ptr(),

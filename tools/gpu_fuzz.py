@@ -85,7 +85,7 @@ def render(t, variant, window=None, fused=False, on_device=False):
         os.environ.pop("CUDABROT_AMD_TWO_LEVEL", None)
     ws_bytes = 0
     if not simple and t["workspace"] != "none":
-        ws_bytes = cb.scatter_workspace_bytes(dims, n, max(t["launch_samples"]))
+        ws_bytes = cb.scatter_workspace_bytes(dims, n, max(t["launch_samples"]), n_channels=max(planes, 1))
         if t["workspace"] == "short":
             ws_bytes = ws_bytes // 3
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)

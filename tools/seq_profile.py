@@ -44,7 +44,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, 0, threads, states.data_ptr(), stream)
     spt = 50 * passes
-    ws_bytes = cb.scatter_workspace_bytes(dims, threads, spt)
+    ws_bytes = cb.scatter_workspace_bytes(dims, threads, spt, n_channels=planes)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
     it = cb.IterationControl(*windows[0])
 
