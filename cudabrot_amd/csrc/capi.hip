@@ -104,6 +104,9 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
     a.tail_value = a.tail_steps ? a.tail_steps : ~0u;
     a.accept_rem = a.max_iter - a.min_iter;
     a.fast_mid = (a.min_iter >= a.head_steps + a.mid_steps && long_steps > 0) ? 1 : 0;
+    a.long_start = a.head_steps + a.mid_steps;
+    a.tail_start = a.long_start + (int) (a.long_steps - a.tail_steps);
+    a.sparse_long = (long_steps > 0 && a.min_iter <= a.long_start && getenv("CUDABROT_AMD_DENSE_TESTS") == nullptr) ? 1 : 0;
   }
   a.n_threads = n_threads;
   a.samples_per_thread = samples_per_thread;

@@ -555,6 +555,126 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
   lane_steps = cnt;
 }
 
+// ---- the same chunk with the escape test on every tenth step only -----------------------------------------
+//
+// Three of the seven instructions of a step exist for the escape test (|z|^2 and the compare).  The LONG
+// stage does not need the step at which an orbit escapes, only WHETHER it escaped inside the chunk (the
+// accept filter goes by chunk, cudabrot.cu:407-408; the REPLAY stage finds the exact index again), and escape
+// is absorbing: with |c| <= 2, |z| > 2 implies |z^2 + c| >= |z|^2 - |c| > |z|.  In fp64 that holds up to
+// rounding: if the reference's test fires at some step (4 |z|^2 = M > 16 on the doubled coordinates), then
+// writing |Z_k| >= 4 - e_k for the steps after it, e' <= 4 e + 2^-39 (|C| <= 4 + 2^-40 for every sample that
+// survives HEAD -- a larger |c| escapes at iteration 0 with margin; rounding of one step <= 2^-44 while |Z| <=
+// 8, beyond that |Z'| >= 28), so nine steps later e <= 2^-21 and M >= 16 - 2^-17, or M is infinite / NaN.
+// The chunk therefore computes |Z|^2 on steps 10, 20 and 30 only and compares it with kSparseThreshold =
+// 16 - 2^-10 (64 times the bound; `le` is false for NaN): a lane above it stops counting as alive.  At the
+// end of the chunk such a lane has escaped for certain if its FINAL M is above 16 (or NaN): escaped at that
+// very step if not before.  What is left -- a lane that was above the threshold at a test step and is at or
+// below 16 at the end: an orbit grazing |z| = 2 without leaving, one test step in 3 x 10^8 -- is decided
+// exactly by recomputing the orbit from z0 = c with the per-step test (verify_chunk_escape below).
+// 8 instructions per step for the two orbits + 6 per test step: 258 per chunk instead of 420, and no scalar
+// bookkeeping inside the chunk: the executed iterations are counted per chunk (kChunk per orbit that ran it)
+// and the over-count of an orbit's last chunk is taken back when REPLAY knows its escape index
+// (long_overcount).  Only used when every escape inside a full LONG chunk is accepted (min_iter <= the start
+// of the LONG stage): an escape that is too fast is never replayed, so its index would stay unknown.
+constexpr double kSparseThreshold = 16.0 - 0x1p-10;
+#define CB_STEP2_NT                                       \
+  "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
+  "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
+  "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
+  "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
+  "v_fma_f64 %[ia], " CB_AL "%[ra]" CB_AR ", " CB_AL "%[ia]" CB_AR ", %[cia]\n\t"             \
+  "v_fma_f64 %[ib], " CB_AL "%[rb]" CB_AR ", " CB_AL "%[ib]" CB_AR ", %[cib]\n\t"             \
+  "v_fma_f64 %[ra], %[a0], 0.5, %[cra]\n\t"               \
+  "v_fma_f64 %[rb], %[a1], 0.5, %[crb]\n\t"
+// the first step after a test step: the masks of that test are applied behind its first instructions
+#define CB_STEP2_NT_AND                                   \
+  "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
+  "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
+  "s_and_b64 %[la], %[la], %[c0]\n\t"                     \
+  "v_fma_f64 %[a0], %[ra], %[ra], -%[a0]\n\t"             \
+  "s_and_b64 %[lb], %[lb], %[c1]\n\t"                     \
+  "v_fma_f64 %[a1], %[rb], %[rb], -%[a1]\n\t"             \
+  "v_fma_f64 %[ia], " CB_AL "%[ra]" CB_AR ", " CB_AL "%[ia]" CB_AR ", %[cia]\n\t"             \
+  "v_fma_f64 %[ib], " CB_AL "%[rb]" CB_AR ", " CB_AL "%[ib]" CB_AR ", %[cib]\n\t"             \
+  "v_fma_f64 %[ra], %[a0], 0.5, %[cra]\n\t"               \
+  "v_fma_f64 %[rb], %[a1], 0.5, %[crb]\n\t"
+// |Z|^2 of both orbits and the test against the threshold
+#define CB_STEP2_TEST                                     \
+  "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
+  "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
+  "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
+  "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
+  "v_cmp_le_f64_e64 %[c0], %[a0], %[kt]\n\t"              \
+  "v_cmp_le_f64_e64 %[c1], %[a1], %[kt]\n\t"
+#define CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT
+constexpr int kSparseStride = 10;  // steps between tests; the bound above is for at most ten
+static_assert(kChunk == 3 * kSparseStride, "the sparse chunk below is written for three groups of ten steps");
+
+// The chunk of iterate_chunk2 with sparse tests.  esc_*: lanes of the masks that stopped counting as alive;
+// sure_*: lanes whose final |Z|^2 is above 16 or NaN (for a lane of esc_*: it escaped inside the chunk for
+// certain).  The caller decides esc & ~sure exactly (verify_chunk_escape).
+__device__ __forceinline__ void iterate_chunk2_sparse(unsigned long long mask_a, unsigned long long mask_b,
+                                                      Orbit &oa, Orbit &ob, unsigned long long &esc_a,
+                                                      unsigned long long &esc_b, unsigned long long &sure_a,
+                                                      unsigned long long &sure_b) {
+  unsigned long long la = mask_a, lb = mask_b, c0, c1, d0, d1;
+  double a0, a1;
+  const double k16 = 16.0, kt = kSparseThreshold;
+  asm volatile(
+      CB_STEP2_NT CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+      CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+      CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+      "v_cmp_nle_f64_e64 %[d0], %[a0], %[k16]\n\t"
+      "v_cmp_nle_f64_e64 %[d1], %[a1], %[k16]\n\t"
+      "s_and_b64 %[la], %[la], %[c0]\n\t"
+      "s_and_b64 %[lb], %[lb], %[c1]\n\t"
+      "s_nop 2\n\t"
+      : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [la] "+s"(la),
+        [lb] "+s"(lb), [a0] "=&v"(a0), [a1] "=&v"(a1),
+        [c0] "=&s"(c0), [c1] "=&s"(c1), [d0] "=&s"(d0), [d1] "=&s"(d1)
+      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci), [k16] "s"(k16), [kt] "s"(kt)
+      : "scc");
+  esc_a = mask_a & ~la;
+  esc_b = mask_b & ~lb;
+  sure_a = d0;
+  sure_b = d1;
+}
+
+// The exact decision for the lanes of `doubt`: did the orbit with starting point (cr, ci) escape during the
+// kChunk iterations after its first `done` ones (lane-wise)?  Recomputed from z0 = c with the reference's
+// test after every step (cudabrot.cu:326-337); the steps before the chunk passed that test when they were
+// made.  Rare (see above), so plain C++ under EXEC: same arithmetic as the asm (device_math.h).
+__device__ __forceinline__ unsigned long long verify_chunk_escape(unsigned long long doubt, const Orbit &o,
+                                                                  int done) {
+  bool escaped = false;
+  if (lane_in(doubt)) {
+    double r = o.cr, i = o.ci;
+    for (int k = 0; k < done; ++k) {
+#ifdef CB_BURNING_SHIP
+      (void) mandel_step2_ship(o.cr, o.ci, r, i);
+#else
+      (void) mandel_step2(o.cr, o.ci, r, i);
+#endif
+    }
+    for (int k = 0; k < kChunk && !escaped; ++k) {
+#ifdef CB_BURNING_SHIP
+      escaped = mandel_step2_ship(o.cr, o.ci, r, i) > 16.0;
+#else
+      escaped = mandel_step2(o.cr, o.ci, r, i) > 16.0;
+#endif
+    }
+  }
+  return __ballot(escaped);
+}
+
+// Iterations the sparse chunks counted beyond the escape of an orbit that took `steps` iterations in all
+// (escape index + 1): an orbit that escaped inside a full LONG chunk was counted to the end of that chunk.
+__device__ __forceinline__ uint32_t long_overcount(int steps, int long_start, int tail_start) {
+  if (steps <= long_start || steps > tail_start) return 0u;  // escaped before the LONG stage / in its exact tail chunk
+  const uint32_t rem = (uint32_t) (steps - long_start) % (uint32_t) kChunk;
+  return rem ? (uint32_t) kChunk - rem : 0u;
+}
+
 // ---- LONG bookkeeping around a chunk, one orbit slot at a time ---------------------------------------
 //
 // long_refill: the idle lanes (l_rem == 0) of the slot take (c, z) from Q1 -- ring slot
@@ -950,6 +1070,7 @@ draw_wave_kernel(DrawArgs a) {
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
   int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
   uint32_t skip_lo = 0, skip_hi = 0;  // per lane, 64 bits: iterations the periodicity check made unnecessary
+  uint32_t over = 0;                  // per lane: iterations the sparse LONG chunks counted beyond an escape
   // REPLAY lane state
   Orbit po = {0, 0, 0, 0};
   bool p_act = false;
@@ -974,6 +1095,7 @@ draw_wave_kernel(DrawArgs a) {
       if (p_real) set &= ~((2u << (p_tag >> a.bin.e_chan_shift)) - 1u);  // the channels still to come
     }
     const bool measured = fin && !p_real;
+    if (measured && a.sparse_long) over += long_overcount(p_steps, a.long_start, a.tail_start);
     n_recorded += (unsigned long long) __popcll(__ballot(measured && set != 0u));
     n_too_fast += (unsigned long long) __popcll(__ballot(measured && set == 0u));  // in no window (cudabrot.cu:407-408 for every channel)
     if (fin && set != 0u) {  // another pass: the same orbit from z = c, recorded into its next channel
@@ -1113,7 +1235,12 @@ draw_wave_kernel(DrawArgs a) {
           n_replay += steps;
           n_incr += hits;
           p_act = lane_in(act_mask);
-          if (multi) channel_decision(was_act & ~act_mask);
+          if (multi) {
+            channel_decision(was_act & ~act_mask);
+          } else if ((was_act & ~act_mask) != 0ull) {  // replays that ended: their escape index is known now
+            const KernelArgs ra = fresh_args();
+            if (ra->sparse_long && lane_in(was_act & ~act_mask)) over += long_overcount(p_steps, ra->long_start, ra->tail_start);
+          }
           if (__ballot(p_act && p_steps > max_iter) != 0ull) {
             // cannot happen: the orbit escaped within max_iter steps in an earlier stage
             status |= CB_STATUS_REPLAY_RUNAWAY;
@@ -1148,7 +1275,10 @@ draw_wave_kernel(DrawArgs a) {
               status |= CB_STATUS_REPLAY_RUNAWAY;
               done = true;
             }
-            if (done) p_act = false;
+            if (done) {
+              p_act = false;
+              if (!multi && a.sparse_long) over += long_overcount(p_steps, a.long_start, a.tail_start);
+            }
           }
           n_incr += (unsigned long long) __popcll(__ballot(hit));
           const unsigned long long done_mask = __ballot(done);
@@ -1372,8 +1502,25 @@ draw_wave_kernel(DrawArgs a) {
       }
       if ((full_mask[0] | full_mask[1]) != 0ull) {
         unsigned long long esc[kOrbitsPerLane];
-        iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], steps);
-        n_iterate += steps;
+        if (la->sparse_long) {  // the escape test on every tenth step (iterate_chunk2_sparse)
+          unsigned long long sure[kOrbitsPerLane];
+          iterate_chunk2_sparse(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], sure[0], sure[1]);
+          n_iterate += (unsigned long long) kChunk *
+                       (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
+          if (((esc[0] & ~sure[0]) | (esc[1] & ~sure[1])) != 0ull) {  // one chunk in ~10^7
+#pragma unroll
+            for (int o = 0; o < kOrbitsPerLane; ++o) {
+              const unsigned long long doubt = esc[o] & ~sure[o];
+              if (doubt != 0ull) {
+                const unsigned long long really = verify_chunk_escape(doubt, lo[o], max_iter - l_rem[o]);
+                esc[o] = (esc[o] & ~doubt) | (really & doubt);
+              }
+            }
+          }
+        } else {
+          iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], steps);
+          n_iterate += steps;
+        }
         if (kTimed) {
           dbg_chunks++;
           dbg_slots += (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
@@ -1450,12 +1597,13 @@ draw_wave_kernel(DrawArgs a) {
     pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32);
   }
   const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
+  const unsigned long long over_total = wave_sum((unsigned long long) over);
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
     const unsigned long long n_samples =
         (unsigned long long) __popcll(valid_mask) * (unsigned long long) a.samples_per_thread;
     const unsigned long long v[9] = {n_samples, n_rejected, n_never,  n_too_fast, n_recorded,
-                                     n_iterate + skipped_total, n_replay, n_incr, skipped_total};
+                                     n_iterate + skipped_total - over_total, n_replay, n_incr, skipped_total};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

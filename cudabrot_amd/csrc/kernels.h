@@ -102,6 +102,11 @@ struct DrawArgs {
   uint32_t long_steps, tail_steps, tail_value;
   int accept_rem;
   int fast_mid;  // the usual split: MID ends at or before min_iter and the LONG stage follows
+  // The LONG stage's chunks test for escape on every tenth step only (draw_wave.hip, iterate_chunk2_sparse):
+  // allowed when every escape inside a full LONG chunk is accepted, i.e. min_iter <= long_start.  long_start:
+  // first iteration of the LONG stage; tail_start: first iteration of an orbit's last, shorter chunk (which
+  // tests every step).
+  int sparse_long, long_start, tail_start;
   // iteration control (cudabrot.cu:62-67)
   int max_iter, min_iter;
   // stage split of draw_wave_kernel (plan_stages): HEAD runs iterations [0, head_steps), MID the
