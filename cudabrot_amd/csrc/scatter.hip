@@ -49,7 +49,7 @@ constexpr uint32_t kMaxKeys = kMaxGroups * kGroupTiles;
 constexpr uint32_t kRegionEntries = 32768;         // entries of one region sort: runs of ~32 entries per tile
 constexpr uint32_t kSortThreads = 1024;
 constexpr uint32_t kSortPerThread = kRegionEntries / kSortThreads;  // 32 entries in registers
-constexpr uint32_t kSliceRegionsDefault = 4096;    // regions one accumulate workgroup gathers from
+constexpr uint32_t kSliceRegionsDefault = 8192;    // most regions one accumulate workgroup gathers from (slice_regions_for)
 constexpr uint32_t kGroupRegionEntries = kRegionEntries - 8u;  // regions cut from a group's stretch (two levels)
 static_assert(kRegionEntries <= 65535, "run_start holds 16-bit positions inside a region");
 
@@ -159,16 +159,33 @@ __global__ void __launch_bounds__(kMaxGroups) bin_group_regions_kernel(BinLayout
   }
 }
 
+// How many regions one accumulate workgroup gathers from.  A workgroup zeroes and flushes a 64 KiB tile, so it
+// wants many regions; the GPU wants thousands of workgroups, and a canvas of few tiles (the reference's 1000 x
+// 1000 default has 64) would otherwise give a few hundred.  pairs = (tile, region) pairs of the launch.
+constexpr uint32_t kSliceTargetGroups = 12288;
+constexpr uint32_t kSliceRegionsMin = 512;  // one run per lane: fewer leave waves of the workgroup without work
+__device__ __forceinline__ uint32_t slice_regions_for(const BinLayout &b, unsigned long long pairs) {
+  unsigned long long s = (pairs + kSliceTargetGroups - 1u) / kSliceTargetGroups;
+  if (s < kSliceRegionsMin) s = kSliceRegionsMin;
+  if (s > b.slice_regions) s = b.slice_regions;
+  return (uint32_t) s;
+}
+
 // slice_base[t] <- number of accumulate workgroups of tiles < t: tile t of group g takes
-// ceil(group_regions[g] / slice_regions) of them.  One workgroup.
+// ceil(group_regions[g] / S) of them, S = slice_regions_for(...) left in n_regions[1].  One workgroup.
 __global__ void __launch_bounds__(1024) bin_slice_table_kernel(BinLayout b) {
   __shared__ uint32_t wave_totals[16];
   const uint32_t nk = b.n_tiles;
   const uint32_t per = (nk + 1023u) / 1024u;  // <= kMaxKeys / 1024
   const uint32_t t0 = threadIdx.x * per;
-  auto slices_of = [&](uint32_t t) {
-    return (b.group_regions[t >> kGroupShift] + b.slice_regions - 1u) / b.slice_regions;
-  };
+  unsigned long long pairs = 0;
+  for (uint32_t g = 0; g < b.n_groups; ++g) {
+    const uint32_t tiles = (nk - (g << kGroupShift)) < kGroupTiles ? (nk - (g << kGroupShift)) : kGroupTiles;
+    pairs += (unsigned long long) tiles * b.group_regions[g];
+  }
+  const uint32_t S = slice_regions_for(b, pairs);
+  if (threadIdx.x == 0) b.n_regions[1] = S;
+  auto slices_of = [&](uint32_t t) { return (b.group_regions[t >> kGroupShift] + S - 1u) / S; };
   uint32_t mine = 0;
   for (uint32_t k = 0; k < per; ++k) {
     if (t0 + k < nk) mine += slices_of(t0 + k);
@@ -196,15 +213,17 @@ __global__ void __launch_bounds__(1024) bin_slice_table_kernel(BinLayout b) {
 // stretches one after another): the stream is far from uniform over the tiles -- at C3 it spreads like 162
 // equally likely tiles, not 1024 -- and LDS atomics of one wave instruction on one address are served one
 // after another.
-constexpr uint32_t kDummyKey = kGroupTiles;
 constexpr uint32_t kDummyPlace = kRegionEntries + 8u;
-#ifndef CB_CNT_REPLICAS
-#define CB_CNT_REPLICAS 2
-#endif
-constexpr uint32_t kCntReplicas = CB_CNT_REPLICAS;
-constexpr uint32_t kCntStride = kGroupTiles + 16;
-constexpr size_t kSortLdsBytes =
-    (kCntReplicas * kCntStride + 16) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
+// Two replicas of 1024 counters, or -- canvases of at most 256 tiles, where the atomics crowd on few counters
+// (the reference's default 1000 x 1000 has 64) -- eight replicas of 256.
+template <bool kFewTiles>
+struct SortLds {
+  static constexpr uint32_t kReplicas = kFewTiles ? 8u : 2u;
+  static constexpr uint32_t kStride = (kFewTiles ? 256u : kGroupTiles) + 16u;  // counters of a replica + the dummy
+  static constexpr size_t kBytes =
+      (kReplicas * kStride + 16) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
+};
+constexpr uint32_t kFewTilesMax = 256;
 
 // kPlain: one plane and the plain word row << 16 | col (every render that is not a fused multi-channel one):
 // tile and offset with constant shifts instead of the layout's run-time fields.
@@ -217,8 +236,10 @@ __device__ __forceinline__ uint32_t sort_word(uint32_t e, uint32_t k0, const Bin
   return ((tile_of(e, b) - k0) << 16) | offset_of(e, b);
 }
 
-template <bool kPlain>
+template <bool kPlain, bool kFewTiles>
 __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b) {
+  constexpr uint32_t kCntReplicas = SortLds<kFewTiles>::kReplicas, kCntStride = SortLds<kFewTiles>::kStride;
+  constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
   extern __shared__ uint32_t lds[];
   uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
@@ -279,10 +300,11 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   __syncthreads();
   // 2. where each tile's run starts: exclusive scan of the counts; published as run_start[tile][region]
   {
+    const bool has_key = threadIdx.x < kDummyKey;  // (with few tiles most threads only take part in the scan)
     uint32_t c[kCntReplicas], sum = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kCntReplicas; ++k) {
-      c[k] = lds[k * kCntStride + threadIdx.x];
+      c[k] = has_key ? lds[k * kCntStride + threadIdx.x] : 0u;
       sum += c[k];
     }
     uint32_t total = 0;
@@ -291,7 +313,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
 #pragma unroll
     for (uint32_t k = 0; k < kCntReplicas; ++k) {
-      lds[k * kCntStride + threadIdx.x] = first;
+      if (has_key) lds[k * kCntStride + threadIdx.x] = first;
       first += c[k];
     }
   }
@@ -347,8 +369,9 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
   const uint32_t k0 = g << kGroupShift;
   const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
   const uint32_t first = b.group_first[g], n_reg = b.group_regions[g];
-  const uint32_t r0 = (s - b.slice_base[t]) * b.slice_regions;
-  const uint32_t r1 = (r0 + b.slice_regions < n_reg) ? r0 + b.slice_regions : n_reg;
+  const uint32_t S = b.n_regions[1];  // regions per slice of this launch (bin_slice_table_kernel)
+  const uint32_t r0 = (s - b.slice_base[t]) * S;
+  const uint32_t r1 = (r0 + S < n_reg) ? r0 + S : n_reg;
 
   for (uint32_t p = threadIdx.x; p < (uint32_t) kTilePixels; p += kAccThreads) tile[p] = 0u;
   __syncthreads();
@@ -734,16 +757,6 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream) {
   if (!b.enabled) return hipSuccess;
-  {  // per call: the attribute belongs to the current device
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_region_sort_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) kSortLdsBytes);  // 68 KiB of the 160 per CU
-    if (e == hipSuccess) {
-      e = hipFuncSetAttribute(reinterpret_cast<const void *>(bin_region_sort_kernel<false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) kSortLdsBytes);
-    }
-    if (e != hipSuccess) return e;
-  }
   if (b.two_level) {
     const uint32_t nk = b.n_groups * kReplicas;
     hipLaunchKernelGGL(group_count_kernel, dim3(b.n_waves), dim3(kScatterThreads), nk * sizeof(uint32_t), stream, b);
@@ -763,14 +776,28 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   hipLaunchKernelGGL(bin_slice_table_kernel, dim3(1), dim3(1024), 0, stream, b);
   const bool plain = b.n_planes == 1u && b.e_row_shift == 16u && b.e_col_mask == 0xffffu && b.e_row_mask == 0xffffu &&
                      b.e_chan_mask == 0u;
-  if (plain) {
-    hipLaunchKernelGGL(bin_region_sort_kernel<true>, dim3(b.max_regions), dim3(kSortThreads), kSortLdsBytes, stream, b);
+  const bool few = b.n_tiles <= kFewTilesMax;
+  const auto launch_sort = [&](auto kernel, size_t lds_bytes) -> hipError_t {
+    // per call: the attribute belongs to the current device
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);  // ~74 KiB of the 160 per CU
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(b.max_regions), dim3(kSortThreads), lds_bytes, stream, b);
+    return hipSuccess;
+  };
+  hipError_t se;
+  if (few) {
+    se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
+               : launch_sort(bin_region_sort_kernel<false, true>, SortLds<true>::kBytes);
   } else {
-    hipLaunchKernelGGL(bin_region_sort_kernel<false>, dim3(b.max_regions), dim3(kSortThreads), kSortLdsBytes, stream, b);
+    se = plain ? launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes)
+               : launch_sort(bin_region_sort_kernel<false, false>, SortLds<false>::kBytes);
   }
+  if (se != hipSuccess) return se;
   // upper bound on the accumulate workgroups: every tile's last, partial slice + the full ones
   const unsigned long long rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
-  const unsigned long long slices = b.n_tiles + rows * b.max_regions / b.slice_regions + 1ull;
+  const unsigned long long by_cap = rows * b.max_regions / b.slice_regions;  // slices of the largest size
+  const unsigned long long slices = b.n_tiles + (by_cap > kSliceTargetGroups ? by_cap : kSliceTargetGroups) + 1ull;
   hipLaunchKernelGGL(bin_gather_accumulate_kernel, dim3((uint32_t) slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
   return hipGetLastError();
 }
