@@ -1145,7 +1145,13 @@ draw_wave_kernel(DrawArgs a) {
       default: __builtin_amdgcn_s_setprio(0); break;
     }
   };
-  if (board_row) post_progress_and_set_priority(a.samples_per_thread);
+  // Wave-uniform conditions of the hot loops as scalars (one s_cmp each): as plain bools the compiler keeps them
+  // as 64-bit lane masks, which live in spill slots and cost a pair of v_readlane per HEAD pass.
+  // (0 / 1 words combined with integer operations, so that a test is one s_cmp of a scalar register)
+  const uint32_t no_board = __builtin_amdgcn_readfirstlane(board_row != nullptr ? 0u : 1u);
+  const uint32_t keep_rest = __builtin_amdgcn_readfirstlane((carry != nullptr && !a.drain) ? 0u : 1u);  // 0: leave in-flight work to the next launch
+  const bool has_board = no_board == 0u;
+  if (has_board) post_progress_and_set_priority(a.samples_per_thread);
   if (carry && carry[0] == 1ull) {  // wave-uniform: the header is one address
     q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
     q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));
@@ -1181,7 +1187,7 @@ draw_wave_kernel(DrawArgs a) {
   for (;;) {
     const bool input_done = (samples_left == 0);
     // with a carry buffer the in-flight work is left for the next launch instead of being drained
-    if (input_done && carry && !a.drain) break;
+    if ((samples_left | keep_rest) == 0u) break;  // input done and the rest is left to the next launch
     const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0) != 0ull;
     const bool draining = input_done && (q0_count == 0) && (q1_count == 0) && !l_any;
     const int n_replaying = __popcll(__ballot(p_act));
@@ -1297,18 +1303,21 @@ draw_wave_kernel(DrawArgs a) {
     // inside this loop only the generator and the queue counters are live-modified, so its back
     // edge is light (the outer loop's carries every orbit register).
     bool replay_ready = false;
+    // the statistics of the asm HEAD / MID passes: 32 bits while the loop runs (one scalar each instead of a
+    // 64-bit pair that lives in spill slots), folded into the launch's counters behind it
+    uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
     for (;;) {
     if (q2_count > 0 && q2_count + n_replaying >= 64) {
       replay_ready = true;
       break;
     }
     const bool feed_input_done = (samples_left == 0);
-    if (feed_input_done && carry && !a.drain) break;  // the rest is left in the queues for the next launch
+    if ((samples_left | keep_rest) == 0u) break;  // the rest is left in the queues for the next launch
     // ---------------------------------------------------------------- HEAD
     if (!feed_input_done && q0_count < 64) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       samples_left--;
-      if (board_row && (samples_left & 31u) == 0u) post_progress_and_set_priority(samples_left);
+      if (((samples_left & 31u) | no_board) == 0u) post_progress_and_set_priority(samples_left);
       if constexpr (fast_head) {  // the usual split (plan_stages): one asm block each for the draw and the test
         double c_re, c_im;
         head_draw(rot, c_re, c_im);  // cudabrot.cu:392-393
@@ -1316,9 +1325,9 @@ draw_wave_kernel(DrawArgs a) {
         uint32_t steps;
         head_test(valid_mask, c_re, c_im, (uint32_t) (q0_head + q0_count), q0_lds, alive0, alive4,
                   steps);  // cudabrot.cu:398, 326-337; survivors -> Q0
-        n_rejected += (unsigned long long) __popcll(valid_mask & ~alive0);
-        n_iterate += steps;
-        n_too_fast += (unsigned long long) __popcll(alive0 & ~alive4);  // escaped before min_iter
+        f_rejected += (uint32_t) __popcll(valid_mask & ~alive0);
+        f_steps += steps;
+        f_too_fast += (uint32_t) __popcll(alive0 & ~alive4);  // escaped before min_iter
         q0_count += __popcll(alive4);
         if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
         if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
@@ -1382,8 +1391,8 @@ draw_wave_kernel(DrawArgs a) {
                  (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
         q0_head = (q0_head + n) & (kQ0Cap - 1);
         q0_count -= n;
-        n_iterate += steps;
-        n_too_fast += (unsigned long long) __popcll(take & ~alive);  // escaped before min_iter
+        f_steps += steps;
+        f_too_fast += (uint32_t) __popcll(take & ~alive);  // escaped before min_iter
         q1_count += __popcll(alive);
         if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
         if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
@@ -1436,8 +1445,11 @@ draw_wave_kernel(DrawArgs a) {
     }
     break;
     }  // feed loop
+    n_rejected += f_rejected;
+    n_too_fast += f_too_fast;
+    n_iterate += f_steps;
     if (replay_ready) continue;
-    if (samples_left == 0 && carry && !a.drain) continue;  // leaves at the top: nothing drawn is lost
+    if ((samples_left | keep_rest) == 0u) continue;  // leaves at the top: nothing drawn is lost
 
     // ---------------------------------------------------------------- LONG
     const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1446,14 +1458,16 @@ draw_wave_kernel(DrawArgs a) {
     const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
     const uint32_t check_flag = (uint32_t) la->check_periodic;
     const int accept_rem = la->accept_rem;
+    uint32_t l_orbit_chunks = 0, l_too_fast = 0, l_never = 0;  // as in the feed loop: 32 bits inside the stage
     for (;;) {
       // Even progress for the waves of a SIMD.  VALU issue goes by priority, then by wave age, so
       // with equal priorities the oldest wave races ahead and the youngest is left to finish alone,
       // where one wave cannot fill the fp64 pipe (measured: the 4 waves of a SIMD ended at 31 / 40 /
       // 53 / 65 ms of a 65 ms kernel).  Each wave therefore walks through the four priority levels
       // as it progresses, offset by its wave slot.
-      if (board_row) {
-        if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(samples_left);
+      if (((long_chunks & (kPrioChunks - 1u)) | no_board) == 0u) {
+        post_progress_and_set_priority(samples_left);
+      } else if (has_board) {
       } else if ((long_chunks & (kPrioChunks - 1u)) == 0u) {
         switch ((wave_slot + long_chunks / kPrioChunks) & 3u) {
           case 0: __builtin_amdgcn_s_setprio(0); break;
@@ -1505,8 +1519,7 @@ draw_wave_kernel(DrawArgs a) {
         if (la->sparse_long) {  // the escape test on every tenth step (iterate_chunk2_sparse)
           unsigned long long sure[kOrbitsPerLane];
           iterate_chunk2_sparse(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], sure[0], sure[1]);
-          n_iterate += (unsigned long long) kChunk *
-                       (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
+          l_orbit_chunks += (uint32_t) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
           if (((esc[0] & ~sure[0]) | (esc[1] & ~sure[1])) != 0ull) {  // one chunk in ~10^7
 #pragma unroll
             for (int o = 0; o < kOrbitsPerLane; ++o) {
@@ -1542,16 +1555,20 @@ draw_wave_kernel(DrawArgs a) {
           long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, uniform_u64(full_mask[o]),
                       uniform_u64(esc[o]), accept_rem, long_steps_u, check_flag, q2_tail, q2_lds, push, ended,
                       periodic);
-          n_too_fast += (unsigned long long) __popcll(esc[o] & ~push);
+          l_too_fast += (uint32_t) __popcll(esc[o] & ~push);
           q2_count += __popcll(push);
           if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-          n_never += (unsigned long long) (__popcll(ended) + __popcll(periodic));
+          l_never += (uint32_t) (__popcll(ended) + __popcll(periodic));
         }
       }
       // leave the stage when another one has work to do
       if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                       // REPLAY can fill every lane
       if (q1_count < kQ1Exit && (samples_left != 0 || q0_count > 0)) break;       // HEAD / MID must top up
+      if (l_orbit_chunks > (1u << 30)) break;                                      // (fold the 32-bit statistics; the stage is re-entered)
     }
+    n_iterate += (unsigned long long) kChunk * l_orbit_chunks;
+    n_too_fast += l_too_fast;
+    n_never += l_never;
     if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
   }
 
