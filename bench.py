@@ -44,7 +44,9 @@ PASSES_PER_STEP = int(os.environ.get("CUDABROT_AMD_BENCH_PASSES", "64"))   # ref
 PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz (spec)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_ITERATION = 10         # 6 mul + 4 add/sub of cudabrot.cu:331-336
-ISSUE_SLOTS_PER_ITERATION = 7    # what the kernel issues per iteration: 6 fp64 instructions (doubled-coordinate step) + 1 compare
+ISSUE_SLOTS_PER_ITERATION = 7    # a tested step: 6 fp64 instructions (doubled-coordinate step) + 1 compare (HEAD, MID, REPLAY)
+LONG_SLOTS_PER_ITERATION = 4.3   # the LONG stage tests for escape on every tenth step: 4 + 3/10 instructions per step
+PRACTICAL_HBM_GBPS = 6290.0      # MI355X_MICROARCH.md: measured float4 copy, the achievable streaming rate
 BYTES_PER_INCREMENT = 16         # u64 read + write per histogram increment
 
 
@@ -81,7 +83,7 @@ def recorded_traffic(samples_per_step):
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_summary.json"))):   # this round's kernels
         try:
             s = json.load(open(f))
             if s["bench_line"]["config"]["samples_per_step_per_gpu"] == samples_per_step:
@@ -142,6 +144,9 @@ def main():
                     help="skip the extra launches that measure the iterate loop with the early-out off")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="A/B: issue the scatter of launch k behind draw k on the same stream instead of on a second "
+                         "stream beside draw k+1 (measured: 2 % slower)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3",
                     help="workload: C3 (default, the config BASELINE.json's metric is quoted on), C4 (20000x20000), C2")
     args = ap.parse_args()
@@ -190,8 +195,8 @@ def main():
     # workspace, so that the scatter's first kernels fill the CUs the draw kernel's tail leaves idle.
     ws_bytes = 0 if args.direct_atomics else cb.scatter_workspace_bytes(dims, threads, samples_per_thread)
     workspaces = [torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
-    flush_stream_t = torch.cuda.Stream(device=dev)
     draw_stream_t = torch.cuda.current_stream()
+    flush_stream_t = draw_stream_t if args.single_stream else torch.cuda.Stream(device=dev)
     flush_stream = flush_stream_t.cuda_stream
     draw_done = [torch.cuda.Event() for _ in range(2)]
     flush_done = [torch.cuda.Event() for _ in range(2)]
@@ -372,7 +377,6 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
-                "issue_frac": round(tflops / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(avg_ms, 4),
                 "alone_ms": round(sum(seq_draw_ms) / len(seq_draw_ms), 4) if seq_draw_ms else None,
                 "frac_alone": round(tflops * avg_ms / (sum(seq_draw_ms) / len(seq_draw_ms)) / PEAK_FP64_VECTOR_TFLOPS, 4)
@@ -380,25 +384,28 @@ def main():
                 "algorithmic_flops_per_launch": iters_per_launch * FLOPS_PER_ITERATION,
                 "traffic": traffic["draw"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
-                "note": "no MFMA: the path has no contraction; 10 flops per z<-z^2+c iteration over the iterations "
-                        "the kernel EXECUTED (counted in-kernel; orbits found exactly periodic are retired early "
-                        "with the identical outcome, so at max_iter=20000 only ~14 % of the reference's iterations "
-                        "are executed); the kernel also draws, tests and replays, so this is a lower bound on its "
-                        "fp64 use; avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the "
-                        "previous launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, "
-                        "after the clock); the kernel executes an iteration as 6 fp64 instructions + 1 compare "
-                        "(doubled-coordinate form of the 10-flop step), so the ceiling of `frac` is 10/14 = 0.714; "
-                        "issue_frac = fp64 issue-slot utilisation (7 per iteration); peak is the 2.4 GHz spec figure, "
-                        "the shader clock under this load is ~2.08 GHz (DESIGN.md 4.4)",
+                "note": "no MFMA: the path has no contraction; 10 ALGORITHMIC flops per z<-z^2+c iteration (the reference's "
+                        "loop body, cudabrot.cu:331-336) over the iterations the kernel EXECUTED (counted in-kernel; orbits "
+                        "found exactly periodic are retired early with the identical outcome, so at max_iter=20000 only "
+                        "~13 % of the reference's iterations are executed).  The kernel spends fewer fp64 instructions than "
+                        "that on most of them: a tested step is 6 fp64 instructions + 1 compare (doubled-coordinate form), "
+                        "and the LONG stage -- escape is absorbing, so it tests every tenth step and decides the rare "
+                        "doubtful lane exactly -- 4.3 per step; it also draws, tests and replays, so `frac` is neither a "
+                        "ceiling-bounded utilisation nor comparable with round 1's (which issued 7 per step everywhere).  "
+                        "avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the previous "
+                        "launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, after the "
+                        "clock); peak is the 2.4 GHz spec figure, the shader clock under this load is ~2.08 GHz (DESIGN.md 4.4)",
             },
             "roofline_scatter": {
                 "bound": "hbm",
-                "kernel": "bin_count/scan/scatter/accumulate kernels" if ws_bytes else "atomics inside draw_wave_kernel",
+                "kernel": "bin_region_sort + bin_gather_accumulate (+ region / slice tables)" if ws_bytes
+                          else "atomics inside draw_wave_kernel",
                 "avg_launch_ms": round(scatter_ms, 4),
                 "achieved": round(scatter_gbps, 2),
                 "peak": PEAK_HBM_GBPS,
                 "unit": "GB/s",
                 "frac": round(scatter_gbps / PEAK_HBM_GBPS, 5),
+                "frac_of_measured_copy_rate": round(scatter_gbps / PRACTICAL_HBM_GBPS, 5),   # against 6.29 TB/s
                 "algorithmic_bytes_per_launch": scatter_incr * BYTES_PER_INCREMENT,
                 "pipelined_ms": round(avg_flush_ms, 4),
                 "traffic": traffic["scatter"] if traffic else None,
@@ -443,7 +450,9 @@ def main():
                 "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
-                "issue_frac": round(ftf / FLOPS_PER_ITERATION * ISSUE_SLOTS_PER_ITERATION / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+                # ~97 % of this variant's iterations are LONG-stage steps (4.3 instructions), the rest tested steps (7)
+                "issue_frac": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
+                                    / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
                 "avg_launch_ms": round(fms, 4),
                 "launch_ms": [round(x, 3) for x in f_each],   # the launches of samples, then the drain launch
                 "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),

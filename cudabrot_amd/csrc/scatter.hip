@@ -381,23 +381,33 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
   const bool last_key = (kl + 1u == nk);  // its runs end where the region ends
   const uint16_t *row1 = row0 + b.max_regions;
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  for (uint32_t base = r0 + wv * 64u; base < r1; base += (kAccThreads / 64u) * 64u) {
+  // a run's description: where it starts (16-byte boundary below it), the entries to skip there, its end
+  struct Run {
+    const uint4 *p4;
+    uint32_t lead, len;
+  };
+  const auto describe = [&](uint32_t base) -> Run {
+    Run run = {reinterpret_cast<const uint4 *>(b.sorted), 0u, 0u};  // lanes without a run load (and ignore) the first bytes
     const uint32_t rr = base + lane;
-    // positions relative to the 16-byte boundary below the run: the run is [lead, len) of what is read
-    const uint4 *p4 = reinterpret_cast<const uint4 *>(b.sorted);  // lanes without a run load (and ignore) its first bytes
-    uint32_t lead = 0, len = 0;
     if (rr < r1) {
       const unsigned long long rs = b.region_start[first + rr];
       const unsigned long long beg = rs + row0[rr];
       const unsigned long long end = rs + (last_key ? b.region_count[first + rr] : (uint32_t) row1[rr]);
-      lead = (uint32_t) (beg & 7ull);
-      len = lead + (uint32_t) (end - beg);
-      if (len == lead) {
-        len = lead = 0u;  // an empty run reads nothing
-      } else {
-        p4 = reinterpret_cast<const uint4 *>(b.sorted + (beg - lead));
+      if (end != beg) {  // an empty run reads nothing
+        run.lead = (uint32_t) (beg & 7ull);
+        run.len = run.lead + (uint32_t) (end - beg);
+        run.p4 = reinterpret_cast<const uint4 *>(b.sorted + (beg - run.lead));
       }
     }
+    return run;
+  };
+  constexpr uint32_t kStep = (kAccThreads / 64u) * 64u;
+  Run next = describe(r0 + wv * 64u);
+  for (uint32_t base = r0 + wv * 64u; base < r1; base += kStep) {
+    const Run run = next;
+    next = describe(base + kStep);  // the next batch's descriptors are on their way while this batch is read
+    const uint32_t lead = run.lead, len = run.len;
+    const uint4 *p4 = run.p4;
     const uint32_t last8 = len ? (len - 1u) >> 3 : 0u;  // loads are unconditional, the index clamped to the run
     for (uint32_t at = 0; __ballot(at < len) != 0ull; at += 32u) {
       if (at < len) {

@@ -19,8 +19,9 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
-KERNELS = ("draw_wave_kernel", "bin_wave_regions_kernel", "bin_count_kernel", "bin_scan_rows_kernel", "bin_scan_keys_kernel",
-           "bin_scatter_kernel", "bin_accumulate_kernel")
+KERNELS = ("draw_wave_kernel", "bin_wave_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
+           "bin_gather_accumulate_kernel", "group_count_kernel", "group_scan_rows_kernel", "group_scan_keys_kernel",
+           "bin_group_regions_kernel", "group_scatter_kernel")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
@@ -74,9 +75,13 @@ out = {
     "pmc": pmc,
     "traffic_bytes_per_launch": {
         "draw_wave_kernel": traffic(["draw_wave_kernel"]),
-        "scatter_kernels": traffic(["bin_wave_regions_kernel", "bin_count_kernel", "bin_scan_rows_kernel", "bin_scan_keys_kernel",
-                                    "bin_scatter_kernel", "bin_accumulate_kernel"]),
-        "note": "per launch of 64 fused passes; fabric-side (TCC_EA) bytes, Infinity-Cache hits included",
+        "scatter_kernels": traffic([k for k in KERNELS if k != "draw_wave_kernel"]),
+        "region_sort": traffic(["bin_region_sort_kernel"]),
+        "gather_accumulate": traffic(["bin_gather_accumulate_kernel"]),
+        "note": "per launch of 64 fused passes; fabric-side (TCC_EA) bytes, Infinity-Cache hits included; FETCH_SIZE is "
+                "doubled for every kernel (the guide's correction for wide coalesced reads: requests of 128 bytes tallied "
+                "at 64) -- calibrated for the streaming reads of draw_wave_kernel and bin_region_sort_kernel, an upper "
+                "bound for bin_gather_accumulate_kernel, whose 16-byte loads of short runs may be served in 64-byte requests",
     },
     "draw_wave_kernel_dispatch_ms": durations,
     "bench_line": bench,
