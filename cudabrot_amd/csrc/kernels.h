@@ -64,6 +64,7 @@ struct BinLayout {
   unsigned long long *region_start;  // [max_regions]     regions of the (grouped) stream: first entry ...
   uint32_t *region_count;         // [max_regions]        ... entries (<= 32768) ...
   uint32_t *region_group;         // [max_regions]        ... and group (0 with one level)
+  uint32_t *owner_first;          // [max(n_waves, groups) + 1]  first region of every wave (one level) / group
   uint32_t *group_first;          // [n_groups]           a group's regions are consecutive: the first ...
   uint32_t *group_regions;        // [n_groups]           ... and how many
   uint32_t *n_regions;            // [1]

@@ -40,7 +40,9 @@ namespace {
 constexpr uint32_t kScatterThreads = 512;          // level A
 constexpr uint32_t kChunkEntries = 8192;           // level A: 16 per thread
 constexpr uint32_t kPerThread = kChunkEntries / kScatterThreads;
-constexpr uint32_t kAccThreads = 512;
+// threads of an accumulate workgroup: 1024 where a workgroup has thousands of runs to walk (one level: 0.1 ms of
+// 1.5 at C3), 512 where a tile has few regions (two levels: 2.2 ms instead of 2.3 at 20000^2)
+constexpr uint32_t kAccThreadsWide = 1024, kAccThreadsNarrow = 512;
 constexpr uint32_t kGroupShift = 10;
 static_assert((1u << kGroupShift) == kGroupTiles, "group = tile >> kGroupShift");
 constexpr uint32_t kReplicas = 4;                  // level-A keys per group (2..8 measured equal at 20000^2; 16: 5 % slower, 64: 15 %)
@@ -99,64 +101,86 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 }
 
 // ---- region tables ---------------------------------------------------------------------------------
+//
+// The stream is cut into regions of at most kRegionEntries entries.  One level: every wave's segment
+// [w * cap, w * cap + count) on its own, all regions in group 0.  Two levels: every group's stretch of `grouped`
+// (a_base, scanned) on its own, in pieces of kGroupRegionEntries (a little short of kRegionEntries: these
+// regions start anywhere, and the sort reads from the 16-byte boundary below).  An OWNER is a wave or a group.
+// bin_region_heads_kernel (one workgroup): owner_first[o] = first region of owner o (exclusive scan of the
+// owners' region counts), n_regions, and the groups' extents.  bin_fill_regions_kernel: one thread per region.
+__device__ __forceinline__ uint32_t owner_count(const BinLayout &b) { return b.two_level ? b.n_groups : b.n_waves; }
+__device__ __forceinline__ void owner_extent(const BinLayout &b, uint32_t o, unsigned long long *begin,
+                                             unsigned long long *entries, uint32_t *piece) {
+  if (b.two_level) {
+    *begin = b.a_base[(size_t) o * kReplicas];
+    *entries = b.a_base[(size_t) (o + 1u) * kReplicas] - *begin;
+    *piece = kGroupRegionEntries;
+  } else {
+    *begin = (unsigned long long) o * b.cap;
+    *entries = wave_count_of(b, o);
+    *piece = kRegionEntries;
+  }
+}
 
-// One level: wave w's segment [w * cap, w * cap + count) is cut into regions of kRegionEntries; all regions
-// belong to group 0.  One workgroup.
-__global__ void __launch_bounds__(1024) bin_wave_regions_kernel(BinLayout b) {
+__global__ void __launch_bounds__(1024) bin_region_heads_kernel(BinLayout b) {
   __shared__ uint32_t wave_totals[16];
-  const uint32_t per = (b.n_waves + 1023u) / 1024u;
-  const uint32_t w0 = threadIdx.x * per;
+  const uint32_t n_owners = owner_count(b);
+  const uint32_t per = (n_owners + 1023u) / 1024u;
+  const uint32_t o0 = threadIdx.x * per;
   uint32_t mine = 0;
   for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t w = w0 + k;
-    if (w < b.n_waves) mine += (wave_count_of(b, w) + kRegionEntries - 1u) / kRegionEntries;
+    if (o0 + k < n_owners) {
+      unsigned long long begin, entries;
+      uint32_t piece;
+      owner_extent(b, o0 + k, &begin, &entries, &piece);
+      mine += (uint32_t) ((entries + piece - 1u) / piece);
+    }
   }
   uint32_t total = 0;
   uint32_t r = block_exclusive_scan(mine, wave_totals, &total);
   for (uint32_t k = 0; k < per; ++k) {
-    const uint32_t w = w0 + k;
-    if (w >= b.n_waves) break;
-    const uint32_t n = wave_count_of(b, w);
-    for (uint32_t s = 0; s < n; s += kRegionEntries, ++r) {
-      b.region_start[r] = (unsigned long long) w * b.cap + s;
-      b.region_count[r] = (n - s) < kRegionEntries ? (n - s) : kRegionEntries;
-      b.region_group[r] = 0u;
+    const uint32_t o = o0 + k;
+    if (o >= n_owners) break;
+    unsigned long long begin, entries;
+    uint32_t piece;
+    owner_extent(b, o, &begin, &entries, &piece);
+    const uint32_t regions = (uint32_t) ((entries + piece - 1u) / piece);
+    b.owner_first[o] = r;
+    if (b.two_level) {
+      b.group_first[o] = r;
+      b.group_regions[o] = regions;
     }
+    r += regions;
   }
   if (threadIdx.x == 0) {
+    b.owner_first[n_owners] = total;
     *b.n_regions = total;
-    b.group_first[0] = 0u;
-    b.group_regions[0] = total;
+    if (!b.two_level) {
+      b.group_first[0] = 0u;
+      b.group_regions[0] = total;
+    }
   }
 }
 
-// Two levels: the region table from the group extents of `grouped` (a_base, scanned): group g's entries
-// are cut into regions of kGroupRegionEntries (a little short of kRegionEntries: these regions start anywhere,
-// and the sort reads from the 16-byte boundary below).  One workgroup, one thread per group.
-__global__ void __launch_bounds__(kMaxGroups) bin_group_regions_kernel(BinLayout b) {
-  __shared__ uint32_t wave_totals[kMaxGroups / 64];
-  const uint32_t g = threadIdx.x;
-  unsigned long long begin = 0, end = 0;
-  uint32_t mine = 0;
-  if (g < b.n_groups) {
-    begin = b.a_base[(size_t) g * kReplicas];
-    end = b.a_base[(size_t) (g + 1) * kReplicas];
-    mine = (uint32_t) ((end - begin + kGroupRegionEntries - 1u) / kGroupRegionEntries);
-  }
-  uint32_t total = 0;
-  const uint32_t first = block_exclusive_scan(mine, wave_totals, &total);
-  if (g == 0) *b.n_regions = total;
-  if (g < b.n_groups) {
-    b.group_first[g] = first;
-    b.group_regions[g] = mine;
-    for (uint32_t k = 0; k < mine; ++k) {
-      const uint32_t r = first + k;
-      const unsigned long long s = begin + (unsigned long long) k * kGroupRegionEntries;
-      b.region_start[r] = s;
-      b.region_count[r] = (uint32_t) ((end - s) < kGroupRegionEntries ? (end - s) : kGroupRegionEntries);
-      b.region_group[r] = g;
+__global__ void __launch_bounds__(256) bin_fill_regions_kernel(BinLayout b) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= *b.n_regions) return;  // the grid is an upper bound
+  uint32_t lo = 0, hi = owner_count(b);  // invariant: owner_first[lo] <= r < owner_first[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (b.owner_first[mid] <= r) {
+      lo = mid;
+    } else {
+      hi = mid;
     }
   }
+  unsigned long long begin, entries;
+  uint32_t piece;
+  owner_extent(b, lo, &begin, &entries, &piece);
+  const unsigned long long offset = (unsigned long long) (r - b.owner_first[lo]) * piece;
+  b.region_start[r] = begin + offset;
+  b.region_count[r] = (uint32_t) ((entries - offset) < piece ? (entries - offset) : piece);
+  b.region_group[r] = b.two_level ? lo : 0u;
 }
 
 // How many regions one accumulate workgroup gathers from.  A workgroup zeroes and flushes a 64 KiB tile, so it
@@ -348,6 +372,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
 
 // One workgroup per (tile, slice of regions).  (Measured too: one workgroup of 1024 threads per PAIR of tiles,
 // whose runs lie side by side -- a third fewer 128-byte lines fetched, half the workgroups per CU: no faster.)
+template <uint32_t kAccThreads>
 __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinLayout b,
                                                                             unsigned long long *hist,
                                                                             int w, int h) {
@@ -646,6 +671,7 @@ size_t fixed_bytes(const Shape &s, uint32_t n_waves, uint32_t max_regions) {
   b += round_up((size_t) max_regions * sizeof(unsigned long long), 256);            // region_start
   b += 2 * round_up((size_t) max_regions * sizeof(uint32_t), 256);                  // region_count/group
   b += 2 * round_up((size_t) kMaxGroups * sizeof(uint32_t), 256);                  // group_first/regions
+  b += round_up(((size_t) (n_waves > kMaxGroups ? n_waves : kMaxGroups) + 1) * sizeof(uint32_t), 256);  // owner_first
   b += 256;                                                                         // n_regions
   b += round_up(rows * max_regions * sizeof(uint16_t), 256);                        // run_start
   b += round_up(((size_t) s.n_tiles + 1) * sizeof(uint32_t), 256);                  // slice_base
@@ -749,6 +775,7 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   b.region_group = carve<uint32_t>(p, (size_t) b.max_regions * sizeof(uint32_t));
   b.group_first = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
   b.group_regions = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
+  b.owner_first = carve<uint32_t>(p, ((size_t) (n_waves > kMaxGroups ? n_waves : kMaxGroups) + 1) * sizeof(uint32_t));
   b.n_regions = carve<uint32_t>(p, 256);
   b.run_start = carve<uint16_t>(p, rows * b.max_regions * sizeof(uint16_t));
   b.slice_base = carve<uint32_t>(p, ((size_t) b.n_tiles + 1) * sizeof(uint32_t));
@@ -772,7 +799,6 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     hipLaunchKernelGGL(group_count_kernel, dim3(b.n_waves), dim3(kScatterThreads), nk * sizeof(uint32_t), stream, b);
     hipLaunchKernelGGL(group_scan_rows_kernel, dim3(nk), dim3(256), 0, stream, b);
     hipLaunchKernelGGL(group_scan_keys_kernel, dim3(1), dim3(1024), 0, stream, b);
-    hipLaunchKernelGGL(bin_group_regions_kernel, dim3(1), dim3(kMaxGroups), 0, stream, b);
     const size_t scatter_lds = ((size_t) 3 * nk + 8 + 2 * kChunkEntries) * sizeof(uint32_t);
     if (scatter_lds > 64 * 1024) {  // 76 KiB at 1024 keys; gfx950 has 160 KiB per workgroup
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(group_scatter_kernel),
@@ -780,9 +806,9 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(group_scatter_kernel, dim3(b.n_waves), dim3(kScatterThreads), scatter_lds, stream, b);
-  } else {
-    hipLaunchKernelGGL(bin_wave_regions_kernel, dim3(1), dim3(1024), 0, stream, b);
   }
+  hipLaunchKernelGGL(bin_region_heads_kernel, dim3(1), dim3(1024), 0, stream, b);
+  hipLaunchKernelGGL(bin_fill_regions_kernel, dim3((b.max_regions + 255u) / 256u), dim3(256), 0, stream, b);
   hipLaunchKernelGGL(bin_slice_table_kernel, dim3(1), dim3(1024), 0, stream, b);
   const bool plain = b.n_planes == 1u && b.e_row_shift == 16u && b.e_col_mask == 0xffffu && b.e_row_mask == 0xffffu &&
                      b.e_chan_mask == 0u;
@@ -808,7 +834,13 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   const unsigned long long rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
   const unsigned long long by_cap = rows * b.max_regions / b.slice_regions;  // slices of the largest size
   const unsigned long long slices = b.n_tiles + (by_cap > kSliceTargetGroups ? by_cap : kSliceTargetGroups) + 1ull;
-  hipLaunchKernelGGL(bin_gather_accumulate_kernel, dim3((uint32_t) slices), dim3(kAccThreads), 0, stream, b, hist, w, h);
+  if (b.two_level) {
+    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsNarrow>, dim3((uint32_t) slices), dim3(kAccThreadsNarrow), 0,
+                       stream, b, hist, w, h);
+  } else {
+    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsWide>, dim3((uint32_t) slices), dim3(kAccThreadsWide), 0,
+                       stream, b, hist, w, h);
+  }
   return hipGetLastError();
 }
 

@@ -19,9 +19,9 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
-KERNELS = ("draw_wave_kernel", "bin_wave_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
+KERNELS = ("draw_wave_kernel", "bin_region_heads_kernel", "bin_fill_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
            "bin_gather_accumulate_kernel", "group_count_kernel", "group_scan_rows_kernel", "group_scan_keys_kernel",
-           "bin_group_regions_kernel", "group_scatter_kernel")
+           "group_scatter_kernel")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
