@@ -122,6 +122,56 @@ def reference_gpu(seconds=6):
             pass
 
 
+def full_iterate_leg(cb, torch, np, dims, it, hist, states, counters, threads, samples_per_thread, stream, workspace,
+                     ws_bytes, dev):
+    """The iterate loop against its roofline: the same launch with the periodicity early-out off, i.e. every sample
+    iterated to max_iter as the reference does (same histogram).  Driven like the product: carry buffer, so that the
+    waves pace themselves by the progress board; six launches and the drain launch that completes them, every
+    executed iteration over all seven."""
+    workspaces = [workspace]
+    # the iterate loop against its roofline: the same launch with the periodicity early-out off,
+    # i.e. every sample iterated to max_iter as the reference does (same histogram)
+    # (driven like the product: carry buffer, so that the waves pace themselves by the progress board; six
+    # launches and the drain launch that completes them, every executed iteration over all seven)
+    counters.zero_()
+    fcarry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    FULL_LAUNCHES = 6
+    fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(FULL_LAUNCHES + 1)]
+    for n, (a, b) in enumerate(fev):
+        a.record()
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads,
+                           samples_per_thread if n < FULL_LAUNCHES else 0, counters.data_ptr(),
+                           cb.CB_KERNEL_FULL_ITERATE,
+                           stream, workspaces[0].data_ptr() if ws_bytes else 0, ws_bytes, fcarry.data_ptr())
+        b.record()
+        if ws_bytes:
+            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+    torch.cuda.synchronize()
+    f_each = [a.elapsed_time(b) for a, b in fev]
+    fms = sum(f_each) / FULL_LAUNCHES    # per launch of samples: the drain launch's time is shared by them
+    fc = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
+    fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / FULL_LAUNCHES
+    ftf = fiters * FLOPS_PER_ITERATION / (fms * 1e-3) / 1e12
+    result = {
+        "bound": "valu_fp64",
+        "kernel": "draw_wave_kernel (CB_KERNEL_FULL_ITERATE: early-out off, %.1f iterations/sample executed)"
+                  % (fiters / (threads * samples_per_thread)),
+        "achieved": round(ftf, 3),
+        "peak": PEAK_FP64_VECTOR_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
+        # ~97 % of this variant's iterations are LONG-stage steps (4.3 instructions), the rest tested steps (7)
+        "issue_frac": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
+                            / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+        "avg_launch_ms": round(fms, 4),
+        "launch_ms": [round(x, 3) for x in f_each],   # the launches of samples, then the drain launch
+        "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
+    }
+    return result
+
+
 def baseline_metric():
     """BASELINE.json's metric, verbatim (`value` is its Msamples/sec part: samples drawn per second of the pass
     loop; the escaping points/s and the HBM GB/s parts are `escaping_points_per_sec` and
@@ -240,6 +290,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- diagnostic legs, BEFORE the clock (not counted in `value`) ----------------------------------------
+    # They used to follow the timed region; run first they also bring the device to its working clocks: the
+    # first launches on an idle GPU take 10 %, 4 %, 2 % ... longer, and the driver's run has five warm-up steps.
+    #
+    # (1) The draw launch and the scatter kernels ALONE, for alone_ms and roofline_scatter: in the pipeline of
+    # the timed region they share the GPU with each other, so their event-to-event times there include waiting
+    # for CUs.  Four sequential launches on one stream, the last two timed.
+    seq_flush_ms, seq_incr, seq_draw_ms = [], [], []
+    if ws_bytes:
+        for n in range(4):
+            before = int(counters.cpu().numpy().view(np.uint64)[7])
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
+            cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
+                               counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
+                               workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
+            d1.record()
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+            c1.record()
+            torch.cuda.synchronize()
+            if n >= 2:
+                seq_draw_ms.append(d0.elapsed_time(d1))
+                seq_flush_ms.append(c0.elapsed_time(c1))
+                seq_incr.append(int(counters.cpu().numpy().view(np.uint64)[7]) - before)
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, 0, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
+        cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+        torch.cuda.synchronize()
+    # (2) the iterate loop against its roofline (one GPU only): see full_iterate_leg
+    full_iterate = None
+    if world == 1 and not args.no_full_iterate:
+        full_iterate = full_iterate_leg(cb, torch, np, dims, it, hist, states, counters, threads, samples_per_thread, stream,
+                                        workspaces[0], ws_bytes, dev)
+
     for _ in range(args.warmup):
         step()
     step(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
@@ -263,37 +350,7 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b, _, _ in ev]   # HIP events on the draw stream: the draw kernel
     flush_ms = [c.elapsed_time(d) for _, _, c, d in ev] if ws_bytes else [0.0]  # ... on the flush stream: the scatter kernels
 
-    # The scatter kernels alone, for roofline_scatter: in the pipeline above they share the GPU with the
-    # next draw launch, so their event-to-event time there includes waiting for CUs.  Two more launches,
-    # outside the clock and not counted in `value`, with the scatter issued behind the draw kernel on the
-    # same stream.
-    counters_timed = counters.clone()
-    seq_flush_ms, seq_incr, seq_draw_ms = [], [], []
-    if ws_bytes:
-        for _ in range(2):
-            before = int(counters.cpu().numpy().view(np.uint64)[7])
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d0.record()
-            cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
-                               counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
-                               workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
-            d1.record()
-            torch.cuda.synchronize()
-            seq_draw_ms.append(d0.elapsed_time(d1))
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
-            c1.record()
-            torch.cuda.synchronize()
-            seq_flush_ms.append(c0.elapsed_time(c1))
-            seq_incr.append(int(counters.cpu().numpy().view(np.uint64)[7]) - before)
-        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, 0, counters.data_ptr(),
-                           cb.CB_KERNEL_DEFAULT, stream, workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
-        cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
-        torch.cuda.synchronize()
-    counters_all = counters.clone()  # timed region + the scatter-timing launches: everything the histogram holds
-    counters.copy_(counters_timed)   # the checks and per-launch figures below are about the timed region
-
+    counters_all = counters.clone()  # everything the histogram holds: the timed region
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -319,8 +376,8 @@ def main():
         samples = world * threads * samples_per_thread * args.steps
         assert cnt["samples"] == samples, (cnt["samples"], samples)
         assert cnt["status"] == 0, "kernel reported an internal invariant violation"
-        # the reduced histogram holds exactly the increments every rank counted (timed region + the two
-        # scatter-timing launches after the clock): the N > 1 path validates itself on every run
+        # the reduced histogram holds exactly the increments every rank counted in the timed region (histogram and
+        # counters were zeroed behind the warm-up): the N > 1 path validates itself on every run
         all_incr = int(counters_all.cpu().numpy().view(np.uint64)[7])
         total_incr = int(hist.sum().item())
         assert total_incr == all_incr, "reduced histogram holds %d increments, the ranks counted %d" % (total_incr, all_incr)
@@ -331,7 +388,7 @@ def main():
         incr_per_launch = loc["increments"] / args.steps
         traffic = recorded_traffic(threads * samples_per_thread)
         tflops = iters_per_launch * FLOPS_PER_ITERATION / (avg_ms * 1e-3) / 1e12
-        if ws_bytes:   # the scatter kernels alone (sequential leg after the clock)
+        if ws_bytes:   # the scatter kernels alone (sequential leg before the clock)
             scatter_ms = sum(seq_flush_ms) / len(seq_flush_ms)
             scatter_incr = sum(seq_incr) / len(seq_incr)
         else:          # direct atomics happen inside the draw kernel
@@ -393,7 +450,7 @@ def main():
                         "doubtful lane exactly -- 4.3 per step; it also draws, tests and replays, so `frac` is neither a "
                         "ceiling-bounded utilisation nor comparable with round 1's (which issued 7 per step everywhere).  "
                         "avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the previous "
-                        "launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, after the "
+                        "launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, before the "
                         "clock); peak is the 2.4 GHz spec figure, the shader clock under this load is ~2.08 GHz (DESIGN.md 4.4)",
             },
             "roofline_scatter": {
@@ -411,52 +468,13 @@ def main():
                 "traffic": traffic["scatter"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "note": "16 B per histogram increment (u64 read+write), increments counted in-kernel, over the time "
-                        "of the scatter kernels run alone (two launches after the clock); pipelined_ms is their "
+                        "of the scatter kernels run alone (two launches before the clock); pipelined_ms is their "
                         "event-to-event time inside the timed region, where they share the GPU with the next "
                         "draw launch; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale)",
             },
         }
-        if world == 1 and not args.no_full_iterate:
-            # the iterate loop against its roofline: the same launch with the periodicity early-out off,
-            # i.e. every sample iterated to max_iter as the reference does (same histogram)
-            # (driven like the product: carry buffer, so that the waves pace themselves by the progress board; six
-            # launches and the drain launch that completes them, every executed iteration over all seven)
-            counters.zero_()
-            fcarry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
-            torch.cuda.synchronize()
-            FULL_LAUNCHES = 6
-            fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                   for _ in range(FULL_LAUNCHES + 1)]
-            for n, (a, b) in enumerate(fev):
-                a.record()
-                cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads,
-                                   samples_per_thread if n < FULL_LAUNCHES else 0, counters.data_ptr(),
-                                   cb.CB_KERNEL_FULL_ITERATE,
-                                   stream, workspaces[0].data_ptr() if ws_bytes else 0, ws_bytes, fcarry.data_ptr())
-                b.record()
-                if ws_bytes:
-                    cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
-            torch.cuda.synchronize()
-            f_each = [a.elapsed_time(b) for a, b in fev]
-            fms = sum(f_each) / FULL_LAUNCHES    # per launch of samples: the drain launch's time is shared by them
-            fc = dict(zip(cnt.keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
-            fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / FULL_LAUNCHES
-            ftf = fiters * FLOPS_PER_ITERATION / (fms * 1e-3) / 1e12
-            line["roofline_full_iterate"] = {
-                "bound": "valu_fp64",
-                "kernel": "draw_wave_kernel (CB_KERNEL_FULL_ITERATE: early-out off, %.1f iterations/sample executed)"
-                          % (fiters / (threads * samples_per_thread)),
-                "achieved": round(ftf, 3),
-                "peak": PEAK_FP64_VECTOR_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
-                # ~97 % of this variant's iterations are LONG-stage steps (4.3 instructions), the rest tested steps (7)
-                "issue_frac": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
-                                    / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
-                "avg_launch_ms": round(fms, 4),
-                "launch_ms": [round(x, 3) for x in f_each],   # the launches of samples, then the drain launch
-                "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
-            }
+        if full_iterate is not None:
+            line["roofline_full_iterate"] = full_iterate
         if world == 1 and not args.no_reference:
             ref = reference_gpu()
             if ref:
