@@ -124,20 +124,30 @@ __device__ __forceinline__ void owner_extent(const BinLayout &b, uint32_t o, uns
 
 __global__ void __launch_bounds__(1024) bin_region_heads_kernel(BinLayout b) {
   __shared__ uint32_t wave_totals[16];
+  __shared__ unsigned long long all_entries;
   const uint32_t n_owners = owner_count(b);
   const uint32_t per = (n_owners + 1023u) / 1024u;
   const uint32_t o0 = threadIdx.x * per;
+  if (threadIdx.x == 0) all_entries = 0ull;
+  __syncthreads();
   uint32_t mine = 0;
+  unsigned long long my_entries = 0;
   for (uint32_t k = 0; k < per; ++k) {
     if (o0 + k < n_owners) {
       unsigned long long begin, entries;
       uint32_t piece;
       owner_extent(b, o0 + k, &begin, &entries, &piece);
       mine += (uint32_t) ((entries + piece - 1u) / piece);
+      my_entries += entries;
     }
   }
+  if (my_entries) __hip_atomic_fetch_add(&all_entries, my_entries, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   uint32_t total = 0;
   uint32_t r = block_exclusive_scan(mine, wave_totals, &total);
+  // (block_exclusive_scan has a barrier behind the atomics above)
+  if (threadIdx.x == 0) {  // entries of the launch, for the slice size (n_regions[2..3] as one 64-bit word)
+    *reinterpret_cast<unsigned long long *>(b.n_regions + 2) = all_entries;
+  }
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t o = o0 + k;
     if (o >= n_owners) break;
@@ -188,9 +198,14 @@ __global__ void __launch_bounds__(256) bin_fill_regions_kernel(BinLayout b) {
 // 1000 default has 64) would otherwise give a few hundred.  pairs = (tile, region) pairs of the launch.
 constexpr uint32_t kSliceTargetGroups = 12288;
 constexpr uint32_t kSliceRegionsMin = 512;  // one run per lane: fewer leave waves of the workgroup without work
-__device__ __forceinline__ uint32_t slice_regions_for(const BinLayout &b, unsigned long long pairs) {
+constexpr uint32_t kSliceEntriesMin = 32768;  // ... and a workgroup should find a few entries per pixel of its tile
+__device__ __forceinline__ uint32_t slice_regions_for(const BinLayout &b, unsigned long long pairs,
+                                                      unsigned long long entries) {
   unsigned long long s = (pairs + kSliceTargetGroups - 1u) / kSliceTargetGroups;
   if (s < kSliceRegionsMin) s = kSliceRegionsMin;
+  // a thin stream (the launch that only drains: a partial region per wave): fewer, longer slices
+  const unsigned long long by_entries = entries ? (kSliceEntriesMin * pairs + entries - 1u) / entries : b.slice_regions;
+  if (s < by_entries) s = by_entries;
   if (s > b.slice_regions) s = b.slice_regions;
   return (uint32_t) s;
 }
@@ -207,7 +222,7 @@ __global__ void __launch_bounds__(1024) bin_slice_table_kernel(BinLayout b) {
     const uint32_t tiles = (nk - (g << kGroupShift)) < kGroupTiles ? (nk - (g << kGroupShift)) : kGroupTiles;
     pairs += (unsigned long long) tiles * b.group_regions[g];
   }
-  const uint32_t S = slice_regions_for(b, pairs);
+  const uint32_t S = slice_regions_for(b, pairs, *reinterpret_cast<const unsigned long long *>(b.n_regions + 2));
   if (threadIdx.x == 0) b.n_regions[1] = S;
   auto slices_of = [&](uint32_t t) { return (b.group_regions[t >> kGroupShift] + S - 1u) / S; };
   uint32_t mine = 0;
@@ -269,8 +284,10 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
   uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16);
 
+  // (One workgroup per region, the grid an upper bound.  A fixed grid of resident workgroups striding over the
+  // regions saves the dispatch of the empty ones but was 12 % slower: the two workgroups of a CU fall into step.)
   const uint32_t r = blockIdx.x;
-  if (r >= *b.n_regions) return;  // the grid is an upper bound
+  if (r >= *b.n_regions) return;
   const uint32_t n = b.region_count[r];
   const unsigned long long start = b.region_start[r];
   const uint32_t *src = (b.two_level ? b.grouped : b.stream) + start;
