@@ -67,12 +67,27 @@ constexpr int kOrbitsPerLane = 2;      // deep orbits a lane iterates side by si
 constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
 constexpr int kQ1Cap = 96;             // MID survivors: (c, z)        (3 KiB per wave)
 constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
-constexpr int kQ1Low = 32;             // run MID while fewer deep orbits than this are queued
-constexpr int kQ1Exit = 8;             // LONG hands over to HEAD / MID below this many
-constexpr int kReplayMin = 40;         // suspend REPLAY below this many busy lanes (unless draining)
-constexpr uint32_t kReplayBurst = 16;  // replay steps per asm burst
+#ifndef CB_Q1_LOW
+#define CB_Q1_LOW 32
+#endif
+#ifndef CB_Q1_EXIT
+#define CB_Q1_EXIT 8
+#endif
+#ifndef CB_REPLAY_MIN
+#define CB_REPLAY_MIN 56
+#endif
+#ifndef CB_REPLAY_BURST
+#define CB_REPLAY_BURST 32
+#endif
+#ifndef CB_PRIO_CHUNKS
+#define CB_PRIO_CHUNKS 32
+#endif
+constexpr int kQ1Low = CB_Q1_LOW;      // run MID while fewer deep orbits than this are queued
+constexpr int kQ1Exit = CB_Q1_EXIT;    // LONG hands over to HEAD / MID below this many
+constexpr int kReplayMin = CB_REPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
+constexpr uint32_t kReplayBurst = CB_REPLAY_BURST;  // replay steps per asm burst
 constexpr uint32_t kBrentBits = 2;     // periodicity check: re-save when the chunk count has no bits below its top 2
-constexpr uint32_t kPrioChunks = 32;   // LONG chunks per priority level in the rotation (power of two)
+constexpr uint32_t kPrioChunks = CB_PRIO_CHUNKS;  // LONG chunks per priority level in the rotation (power of two)
 
 // The ring capacities are exact worst cases, not estimates: a stage runs only while its output ring can take
 // everything the stage may push (CB_STATUS_QUEUE_OVERFLOW guards the reasoning, these guard the constants).
