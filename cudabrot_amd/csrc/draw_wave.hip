@@ -932,7 +932,24 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
   "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
   "s_mov_b64 exec, vcc\n\t"                               \
-  "global_store_dword %[pidx], %[e], %[base]\n\t"         \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"
+// kCount (canvases beyond 1024 tiles, BinLayout::count_in_draw): the level-A counts of the two-level sort are
+// made here, where every stream word is born, instead of by a pass over the stream (scatter.hip, group_count):
+// key = (tile >> 10) * 4 + (index of the word in the wave's segment & 3), one ds_add per word into the wave's
+// counters.  EXEC = the lanes that stored a word; row and col are free once the word is formed.
+#define CB_REPLAY_COUNT                                   \
+  "v_lshrrev_b32 %[pl], %[chs], %[tag]\n\t"               \
+  "v_lshrrev_b32 %[row], 7, %[row]\n\t"                   \
+  "v_lshrrev_b32 %[col], 7, %[col]\n\t"                   \
+  "v_mad_u32_u24 %[row], %[pl], %[tly], %[row]\n\t"       \
+  "v_mad_u32_u24 %[row], %[row], %[tlx], %[col]\n\t"      \
+  "v_bfe_u32 %[col], %[pidx], 2, 2\n\t"                   \
+  "v_lshrrev_b32 %[row], 10, %[row]\n\t"                  \
+  "v_lshl_or_b32 %[row], %[row], 2, %[col]\n\t"           \
+  "v_mov_b32 %[col], 1\n\t"                               \
+  "v_lshl_add_u32 %[row], %[row], 2, %[gcl]\n\t"          \
+  "ds_add_u32 %[row], %[col]\n\t"
+#define CB_REPLAY_TAIL2                                   \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
   "s_and_b64 %[act], %[act], %[alive]\n\t"                \
@@ -957,16 +974,16 @@ __device__ __forceinline__ KernelArgs fresh_args() {
   return p;
 }
 
-template <bool kPow2>
+template <bool kPow2, bool kCount>
 __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                              int &p_steps, const Canvas &cv, uint32_t *region,
                                              uint32_t &fill, uint32_t &lane_steps, uint32_t &hits,
                                              uint32_t row_shift, uint32_t tag,
-                                             unsigned long long emit) {
+                                             unsigned long long emit, uint32_t group_counts_lds) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
-  uint32_t col, row, pidx, e;
+  uint32_t col, row, pidx, e, pl;
   // All "s" operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
   (void) cv;
   const KernelArgs ka = fresh_args();
@@ -979,12 +996,49 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   row_shift = __builtin_amdgcn_readfirstlane(row_shift);
   emit = uniform_u64(emit);
   const double k16 = 16.0;
-  if (kPow2) {
+  // kCount: the layout of the tile grid (scalar loads like the rest) and the wave's counters in LDS
+  const uint32_t tlx = kCount ? ka->bin.tiles_x : 0u, tly = kCount ? ka->bin.tiles_y : 0u;
+  const uint32_t chs = kCount ? ka->bin.e_chan_shift : 0u;
+  group_counts_lds = __builtin_amdgcn_readfirstlane(group_counts_lds);
+#define CB_REPLAY_COUNT_OPERANDS , [tlx] "s"(tlx), [tly] "s"(tly), [chs] "s"(chs), [gcl] "s"(group_counts_lds)
+  if (kPow2 && kCount) {
+    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL CB_REPLAY_COUNT CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
+                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
+                 : "vcc", "scc", "memory");
+  } else if (kCount) {
+    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+    const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
+    const double kg = 0.5 - 0x1p-24;
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL CB_REPLAY_COUNT CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
+                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
+                 : "vcc", "scc", "memory");
+  } else if (kPow2) {
     // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
     // a VALU instruction reads one scalar operand
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
@@ -1000,7 +1054,7 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
@@ -1023,12 +1077,21 @@ __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot 
 //
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
-template <bool kTimed, bool kBinned, bool kFastHead>
+template <bool kTimed, bool kBinned, bool kFastHead, bool kCount>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(104)))
 draw_wave_kernel(DrawArgs a) {
   static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
+  static_assert(!kCount || kBinned, "the level-A counts are counts of stream words");
   __shared__ WaveQueues queues[kWavesPerBlock];
   WaveQueues &q = queues[threadIdx.x >> 6];
+  // kCount: this wave's level-A counters of the two-level sort (CB_REPLAY_COUNT), 1 KiB per wave
+  __shared__ uint32_t group_counts[kCount ? kWavesPerBlock : 1][kCount ? kDrawCountKeys : 1];
+  uint32_t *const my_counts = group_counts[kCount ? (threadIdx.x >> 6) : 0];
+  if (kCount) {
+    for (uint32_t k = threadIdx.x & 63u; k < kDrawCountKeys; k += 64u) my_counts[k] = 0u;
+  }
+  const uint32_t group_counts_lds = kCount ? __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(my_counts))) : 0u;
 
   // kBinned: this wave's region of the pixel stream (kernels.h, BinLayout)
   const uint32_t wave_id =
@@ -1247,11 +1310,11 @@ draw_wave_kernel(DrawArgs a) {
           const unsigned long long emit = multi ? __ballot(p_real) : ~0ull;
           uint32_t steps = 0, hits = 0;
           if (cv.pow2_real && cv.pow2_imag) {
-            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                               a.bin.e_row_shift, p_tag, emit);
+            replay_burst<true, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds);
           } else {
-            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                a.bin.e_row_shift, p_tag, emit);
+            replay_burst<false, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds);
           }
           n_replay += steps;
           n_incr += hits;
@@ -1600,6 +1663,16 @@ draw_wave_kernel(DrawArgs a) {
   }
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
   if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
+  if (kBinned && a.bin.draw_counted != nullptr) {
+    // who made the level-A counts of this launch's stream: this kernel (kCount) or nobody yet (group_count_kernel will)
+    if (wave_id == 0u && lane_id() == 0) *a.bin.draw_counted = kCount ? 1u : 0u;
+    if (kCount) {  // a_count[key][wave], as group_count_kernel lays it out
+      const uint32_t n_keys = a.bin.n_groups * kGroupReplicas;
+      for (uint32_t k = (uint32_t) lane_id(); k < n_keys; k += 64u) {
+        a.bin.a_count[(size_t) k * a.bin.n_waves + wave_id] = my_counts[k];
+      }
+    }
+  }
   if (carry) {  // leave queues and orbit slots for the next launch (empty after a drain)
     if (lane_id() == 0) {
       carry[0] = 1ull;
@@ -1683,18 +1756,24 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   // survivors always have iterations left
   const bool fast = (a.head_steps == 4) && (a.min_iter >= 4) && (a.max_iter > 4);
   const dim3 grid(blocks), block(threads);
-#define CB_LAUNCH(T, B, F) hipLaunchKernelGGL((draw_wave_kernel<T, B, F>), grid, block, 0, stream, a)
+  // the level-A counts of the two-level sort made in the REPLAY burst (the product instances only)
+  const bool count = binned && !timed && a.bin.count_in_draw != 0u;
+#define CB_LAUNCH(T, B, F, C) hipLaunchKernelGGL((draw_wave_kernel<T, B, F, C>), grid, block, 0, stream, a)
   if (timed) {
     if (binned) {
-      if (fast) CB_LAUNCH(true, true, true); else CB_LAUNCH(true, true, false);
+      if (fast) CB_LAUNCH(true, true, true, false); else CB_LAUNCH(true, true, false, false);
     } else {
-      if (fast) CB_LAUNCH(true, false, true); else CB_LAUNCH(true, false, false);
+      if (fast) CB_LAUNCH(true, false, true, false); else CB_LAUNCH(true, false, false, false);
     }
   } else {
     if (binned) {
-      if (fast) CB_LAUNCH(false, true, true); else CB_LAUNCH(false, true, false);
+      if (count) {
+        if (fast) CB_LAUNCH(false, true, true, true); else CB_LAUNCH(false, true, false, true);
+      } else {
+        if (fast) CB_LAUNCH(false, true, true, false); else CB_LAUNCH(false, true, false, false);
+      }
     } else {
-      if (fast) CB_LAUNCH(false, false, true); else CB_LAUNCH(false, false, false);
+      if (fast) CB_LAUNCH(false, false, true, false); else CB_LAUNCH(false, false, false, false);
     }
   }
 #undef CB_LAUNCH

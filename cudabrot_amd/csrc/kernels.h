@@ -34,6 +34,8 @@ constexpr int kTileSize = 1 << kTileShift;          // 128 x 128 pixels
 constexpr int kTilePixels = kTileSize * kTileSize;  // 16384 u32 counters = 64 KiB of LDS
 constexpr uint32_t kGroupTiles = 1024;              // keys of one region sort; more tiles: two levels
 constexpr uint32_t kMinRegionEntries = 4096;        // below this per wave the workspace is not used
+constexpr uint32_t kGroupReplicas = 4;              // level-A keys per group of the two-level sort (scatter.hip)
+constexpr uint32_t kDrawCountKeys = 256;            // level-A counters a draw wave keeps in LDS (count_in_draw)
 
 struct BinLayout {
   uint32_t enabled;     // 0: REPLAY adds to the histogram directly
@@ -47,6 +49,9 @@ struct BinLayout {
   // group's stretch of `grouped`, so that a region holds tiles of one group only; scatter.hip
   uint32_t two_level;
   uint32_t n_groups;    // 1 with one level
+  // two levels and n_groups * kGroupReplicas <= kDrawCountKeys: the draw kernel's REPLAY burst makes the level-A
+  // counts (a_count) itself and says so in *draw_counted; group_count_kernel then has nothing to do
+  uint32_t count_in_draw;
   uint32_t max_regions;   // size of the region table and row length of run_start
   // Layout of a stream word: col in the low bits, row above it (e_row_shift), and -- fused multi-channel
   // renders only -- the index of the channel (plane) the point goes to above both (e_chan_shift,
@@ -67,7 +72,8 @@ struct BinLayout {
   uint32_t *owner_first;          // [max(n_waves, groups) + 1]  first region of every wave (one level) / group
   uint32_t *group_first;          // [n_groups]           a group's regions are consecutive: the first ...
   uint32_t *group_regions;        // [n_groups]           ... and how many
-  uint32_t *n_regions;            // [1]
+  uint32_t *n_regions;            // [1] (+ the slice size and the entries of the launch behind it)
+  uint32_t *draw_counted;         // [1] 1: this launch's a_count comes from the draw kernel
   uint16_t *run_start;            // [min(n_tiles, 1024)][max_regions]  where tile k0 + i's run starts in a region
   uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate workgroups per tile
   uint16_t *sorted;               // [n_waves * cap]      in-tile offsets, every region sorted by tile in place

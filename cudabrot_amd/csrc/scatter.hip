@@ -45,7 +45,7 @@ constexpr uint32_t kPerThread = kChunkEntries / kScatterThreads;
 constexpr uint32_t kAccThreadsWide = 1024, kAccThreadsNarrow = 512;
 constexpr uint32_t kGroupShift = 10;
 static_assert((1u << kGroupShift) == kGroupTiles, "group = tile >> kGroupShift");
-constexpr uint32_t kReplicas = 4;                  // level-A keys per group (2..8 measured equal at 20000^2; 16: 5 % slower, 64: 15 %)
+constexpr uint32_t kReplicas = kGroupReplicas;     // level-A keys per group (2..8 measured equal at 20000^2; 16: 5 % slower, 64: 15 %)
 constexpr uint32_t kMaxGroups = 256;               // -> 262144 tiles (all planes of a fused render together)
 constexpr uint32_t kMaxKeys = kMaxGroups * kGroupTiles;
 constexpr uint32_t kRegionEntries = 32768;         // entries of one region sort: runs of ~32 entries per tile
@@ -504,6 +504,7 @@ __device__ __forceinline__ uint32_t group_key(const BinLayout &b, uint32_t e, ui
 
 __global__ void __launch_bounds__(kScatterThreads) group_count_kernel(BinLayout b) {
   extern __shared__ uint32_t lds[];  // [n_groups * kReplicas]
+  if (*b.draw_counted != 0u) return;  // the draw kernel counted its words as it wrote them (CB_REPLAY_COUNT)
   const uint32_t r = blockIdx.x;
   const uint32_t n = wave_count_of(b, r);
   const uint32_t *src = b.stream + (size_t) r * b.cap;  // 16-byte aligned: cap is a multiple of 8
@@ -794,6 +795,8 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   b.group_regions = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
   b.owner_first = carve<uint32_t>(p, ((size_t) (n_waves > kMaxGroups ? n_waves : kMaxGroups) + 1) * sizeof(uint32_t));
   b.n_regions = carve<uint32_t>(p, 256);
+  b.draw_counted = b.n_regions + 8;
+  b.count_in_draw = (b.two_level && b.n_groups * kReplicas <= kDrawCountKeys) ? 1u : 0u;
   b.run_start = carve<uint16_t>(p, rows * b.max_regions * sizeof(uint16_t));
   b.slice_base = carve<uint32_t>(p, ((size_t) b.n_tiles + 1) * sizeof(uint32_t));
   if (b.two_level) {
