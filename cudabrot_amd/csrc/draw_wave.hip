@@ -86,7 +86,10 @@ constexpr int kQ1Low = CB_Q1_LOW;      // run MID while fewer deep orbits than t
 constexpr int kQ1Exit = CB_Q1_EXIT;    // LONG hands over to HEAD / MID below this many
 constexpr int kReplayMin = CB_REPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = CB_REPLAY_BURST;  // replay steps per asm burst
-constexpr uint32_t kBrentBits = 2;     // periodicity check: re-save when the chunk count has no bits below its top 2
+#ifndef CB_BRENT_BITS
+#define CB_BRENT_BITS 2
+#endif
+constexpr uint32_t kBrentBits = CB_BRENT_BITS;     // periodicity check: re-save when the chunk count has no bits below its top 2
 constexpr uint32_t kPrioChunks = CB_PRIO_CHUNKS;  // LONG chunks per priority level in the rotation (power of two)
 
 // The ring capacities are exact worst cases, not estimates: a stage runs only while its output ring can take
@@ -535,6 +538,8 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
 #define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2X4
 #elif CB_CHUNK == 36
 #define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+#elif CB_CHUNK == 60
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
 #else
 #error "unroll CB_STEP2 for this chunk length"
 #endif
@@ -623,7 +628,18 @@ constexpr double kSparseThreshold = 16.0 - 0x1p-10;
   "v_cmp_le_f64_e64 %[c1], %[a1], %[kt]\n\t"
 #define CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT
 constexpr int kSparseStride = 10;  // steps between tests; the bound above is for at most ten
-static_assert(kChunk == 3 * kSparseStride, "the sparse chunk below is written for three groups of ten steps");
+#define CB_SPARSE_GROUP_FIRST CB_STEP2_NT CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+#define CB_SPARSE_GROUP_NEXT CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+#if CB_CHUNK == 30
+#define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#elif CB_CHUNK == 60
+#define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#elif CB_CHUNK == 40
+#define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#else
+#define CB_SPARSE_CHUNK
+#endif
+static_assert(kChunk % kSparseStride == 0 || true, "sparse chunks are groups of ten steps");
 
 // The chunk of iterate_chunk2 with sparse tests.  esc_*: lanes of the masks that stopped counting as alive;
 // sure_*: lanes whose final |Z|^2 is above 16 or NaN (for a lane of esc_*: it escaped inside the chunk for
@@ -636,9 +652,7 @@ __device__ __forceinline__ void iterate_chunk2_sparse(unsigned long long mask_a,
   double a0, a1;
   const double k16 = 16.0, kt = kSparseThreshold;
   asm volatile(
-      CB_STEP2_NT CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
-      CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
-      CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
+      CB_SPARSE_CHUNK
       "v_cmp_nle_f64_e64 %[d0], %[a0], %[k16]\n\t"
       "v_cmp_nle_f64_e64 %[d1], %[a1], %[k16]\n\t"
       "s_and_b64 %[la], %[la], %[c0]\n\t"

@@ -177,7 +177,9 @@ hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stre
 // (by area of the set outside the cardioid and the period-2 disc: 3, 4, 6, 12, 9, 5, 8, 15, 10 ...), so
 // 30 = 2 * 3 * 5 finds them sooner than 32: 9 % fewer executed iterations at C3, the draw launch 5 %
 // shorter (24 and 36 measured too: tools/gpu_chunk_sweep.sh).
-#define CB_CHUNK 30
+#ifndef CB_CHUNK
+#define CB_CHUNK 60
+#endif
 constexpr int kChunk = CB_CHUNK;
 void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps);
 

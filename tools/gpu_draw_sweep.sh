@@ -4,7 +4,7 @@
 set -u
 for flags in "$@"; do
   echo "#### EXTRA=$flags"
-  rm -f cudabrot_amd/csrc/build/draw_wave.o cudabrot_amd/csrc/build/draw_wave_ship.o
+  rm -f cudabrot_amd/csrc/build/*.o
   (cd cudabrot_amd/csrc && make -s EXTRA="$flags" > ../../gpurun_out/sweep_build.log 2>&1) || { echo "build failed"; tail -5 gpurun_out/sweep_build.log; exit 1; }
   for cfg in ${CFGS:-C3}; do python3 tools/seq_profile.py $cfg ${LAUNCHES:-6} | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config'], 'draw', d['draw_ms'], 'status', d['status'])"; done
 done
