@@ -176,7 +176,9 @@ hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stre
 // p is seen p / gcd(p, chunk) chunks after the save.  The periods that matter are mostly multiples of 3
 // (by area of the set outside the cardioid and the period-2 disc: 3, 4, 6, 12, 9, 5, 8, 15, 10 ...), so
 // 30 = 2 * 3 * 5 finds them sooner than 32: 9 % fewer executed iterations at C3, the draw launch 5 %
-// shorter (24 and 36 measured too: tools/gpu_chunk_sweep.sh).
+// shorter (24 and 36 measured too: tools/gpu_chunk_sweep.sh).  With the sparse escape tests (draw_wave.hip,
+// iterate_chunk2_sparse) a chunk of 30 had become so short that the bookkeeping between chunks was a sixth
+// of it: 60 = 4 * 3 * 5 executes 5 % more iterations and is 5 % faster (tools/gpu_draw_sweep.sh).
 #ifndef CB_CHUNK
 #define CB_CHUNK 60
 #endif
