@@ -263,6 +263,10 @@ struct SortLds {
       (kReplicas * kStride + 16) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
 };
 constexpr uint32_t kFewTilesMax = 256;
+#ifndef CB_SORT_GRID
+#define CB_SORT_GRID 32768
+#endif
+constexpr uint32_t kSortGrid = CB_SORT_GRID;  // workgroups of the region sort (each takes every kSortGrid-th region)
 
 // kPlain: one plane and the plain word row << 16 | col (every render that is not a fused multi-channel one):
 // tile and offset with constant shifts instead of the layout's run-time fields.
@@ -284,15 +288,18 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
   uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16);
 
-  // (One workgroup per region, the grid an upper bound.  A fixed grid of resident workgroups striding over the
-  // regions saves the dispatch of the empty ones but was 12 % slower: the two workgroups of a CU fall into step.)
-  const uint32_t r = blockIdx.x;
-  if (r >= *b.n_regions) return;
+  // The grid is kSortGrid workgroups striding over the regions: how many regions a launch has is only known on
+  // the device, and a grid sized for the most it could have spends 11 ns on every workgroup that finds nothing
+  // to do (0.25 ms of a steady launch, 0.7 ms of a drain launch's thin stream).  (A grid of just the 512
+  // resident workgroups was 12 % slower: the two workgroups of a CU fall into step.)
+  const uint32_t n_regions = *b.n_regions;
+  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
   const uint32_t n = b.region_count[r];
   const unsigned long long start = b.region_start[r];
   const uint32_t *src = (b.two_level ? b.grouped : b.stream) + start;
   const uint32_t k0 = b.region_group[r] << kGroupShift;
   const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
+  __syncthreads();  // (a further region of this workgroup: the previous image has left)
   for (uint32_t t = threadIdx.x; t < kCntReplicas * kCntStride; t += kSortThreads) lds[t] = 0u;
   __syncthreads();
 
@@ -383,6 +390,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   } else {
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
   }
+  }  // regions of this workgroup
 }
 
 // ---- gather + accumulate ---------------------------------------------------------------------------
@@ -838,7 +846,8 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);  // ~74 KiB of the 160 per CU
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, dim3(b.max_regions), dim3(kSortThreads), lds_bytes, stream, b);
+    const uint32_t grid = b.max_regions < kSortGrid ? b.max_regions : kSortGrid;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSortThreads), lds_bytes, stream, b);
     return hipSuccess;
   };
   hipError_t se;
