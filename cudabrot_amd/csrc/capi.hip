@@ -107,6 +107,11 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
     a.long_start = a.head_steps + a.mid_steps;
     a.tail_start = a.long_start + (int) (a.long_steps - a.tail_steps);
     a.sparse_long = (long_steps > 0 && a.min_iter <= a.long_start && getenv("CUDABROT_AMD_DENSE_TESTS") == nullptr) ? 1 : 0;
+    a.sparse_threshold = 16.0 - 0x1p-10;
+    if (const char *e = getenv("CUDABROT_AMD_SPARSE_THRESHOLD")) {  // test knob: only ever lower
+      const double v = atof(e);
+      if (v > 0.0 && v < a.sparse_threshold) a.sparse_threshold = v;
+    }
   }
   a.n_threads = n_threads;
   a.samples_per_thread = samples_per_thread;

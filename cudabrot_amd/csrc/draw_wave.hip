@@ -647,10 +647,10 @@ static_assert(kChunk % kSparseStride == 0 || true, "sparse chunks are groups of 
 __device__ __forceinline__ void iterate_chunk2_sparse(unsigned long long mask_a, unsigned long long mask_b,
                                                       Orbit &oa, Orbit &ob, unsigned long long &esc_a,
                                                       unsigned long long &esc_b, unsigned long long &sure_a,
-                                                      unsigned long long &sure_b) {
+                                                      unsigned long long &sure_b, double threshold) {
   unsigned long long la = mask_a, lb = mask_b, c0, c1, d0, d1;
   double a0, a1;
-  const double k16 = 16.0, kt = kSparseThreshold;
+  const double k16 = 16.0, kt = threshold;  // kSparseThreshold, or a test's lower one (DrawArgs::sparse_threshold)
   asm volatile(
       CB_SPARSE_CHUNK
       "v_cmp_nle_f64_e64 %[d0], %[a0], %[k16]\n\t"
@@ -1610,7 +1610,8 @@ draw_wave_kernel(DrawArgs a) {
         unsigned long long esc[kOrbitsPerLane];
         if (la->sparse_long) {  // the escape test on every tenth step (iterate_chunk2_sparse)
           unsigned long long sure[kOrbitsPerLane];
-          iterate_chunk2_sparse(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], sure[0], sure[1]);
+          iterate_chunk2_sparse(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], sure[0], sure[1],
+                                la->sparse_threshold);
           l_orbit_chunks += (uint32_t) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
           if (((esc[0] & ~sure[0]) | (esc[1] & ~sure[1])) != 0ull) {  // one chunk in ~10^7
 #pragma unroll

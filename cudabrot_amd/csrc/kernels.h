@@ -114,6 +114,10 @@ struct DrawArgs {
   // first iteration of the LONG stage; tail_start: first iteration of an orbit's last, shorter chunk (which
   // tests every step).
   int sparse_long, long_start, tail_start;
+  // what |Z|^2 is compared with at a sparse test step: 16 - 2^-10 (draw_wave.hip, kSparseThreshold).  Any value
+  // up to that gives the same result -- a lower one only sends more lanes through the exact decision
+  // (CUDABROT_AMD_SPARSE_THRESHOLD: how the tests drive that path, which otherwise runs once in 3e8 test steps)
+  double sparse_threshold;
   // iteration control (cudabrot.cu:62-67)
   int max_iter, min_iter;
   // stage split of draw_wave_kernel (plan_stages): HEAD runs iterations [0, head_steps), MID the

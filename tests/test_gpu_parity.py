@@ -501,3 +501,31 @@ def test_renderer_prepare_allocates_ahead_and_changes_nothing(cb, oracle):
         r.prepare(cb.CB_KERNEL_SIMPLE)          # the lock-step kernel needs no workspace
         r.render_passes(passes, cb.CB_KERNEL_SIMPLE)
         assert np.array_equal(r.read_histogram(), ref)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(w=512, h=512, max_iter=20000, min_iter=20, threads=8192, passes=2),
+    dict(w=333, h=77, max_iter=3000, min_iter=10, threads=4096, passes=3, box=(-1.7, 0.9, -0.3, 1.1)),
+], ids=["deep", "odd_canvas"])
+def test_sparse_escape_tests_change_nothing_but_the_work(cb, oracle, monkeypatch, cfg):
+    """The LONG stage tests for escape on every tenth step only (escape is absorbing) and decides a lane that was
+    above the threshold at a test step but is not above 4 at the end of the chunk exactly, by recomputing its
+    orbit.  Same histogram and the same counters as with the test on every step (CUDABROT_AMD_DENSE_TESTS) -- and
+    with the threshold lowered to |z|^2 = 2 (CUDABROT_AMD_SPARSE_THRESHOLD = 8 on the doubled coordinates), which
+    sends a large share of the orbits through the exact decision that otherwise runs once in 3e8 test steps."""
+    box = cfg.pop("box", BOX)
+    cpu = oracle.render(cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    sparse = gpu_render(cb, box=box, **cfg)
+    monkeypatch.setenv("CUDABROT_AMD_DENSE_TESTS", "1")
+    dense = gpu_render(cb, box=box, **cfg)
+    monkeypatch.delenv("CUDABROT_AMD_DENSE_TESTS")
+    monkeypatch.setenv("CUDABROT_AMD_SPARSE_THRESHOLD", "8.0")
+    doubting = gpu_render(cb, box=box, **cfg)
+    monkeypatch.setenv("CUDABROT_AMD_SPARSE_THRESHOLD", "0.5")     # nearly every lane, at nearly every test step
+    doubting_all = gpu_render(cb, box=box, **dict(cfg, passes=1))
+    cpu1 = oracle.render(cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], 1, box)
+    assert_same(sparse, cpu)
+    assert_same(dense, cpu)
+    assert_same(doubting, cpu)
+    assert_same(doubting_all, cpu1)
+    assert sparse[1]["skipped_steps"] == dense[1]["skipped_steps"] == doubting[1]["skipped_steps"]
