@@ -585,13 +585,13 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 // writing |Z_k| >= 4 - e_k for the steps after it, e' <= 4 e + 2^-39 (|C| <= 4 + 2^-40 for every sample that
 // survives HEAD -- a larger |c| escapes at iteration 0 with margin; rounding of one step <= 2^-44 while |Z| <=
 // 8, beyond that |Z'| >= 28), so nine steps later e <= 2^-21 and M >= 16 - 2^-17, or M is infinite / NaN.
-// The chunk therefore computes |Z|^2 on steps 10, 20 and 30 only and compares it with kSparseThreshold =
+// The chunk therefore computes |Z|^2 on every tenth step only and compares it with kSparseThreshold =
 // 16 - 2^-10 (64 times the bound; `le` is false for NaN): a lane above it stops counting as alive.  At the
 // end of the chunk such a lane has escaped for certain if its FINAL M is above 16 (or NaN): escaped at that
 // very step if not before.  What is left -- a lane that was above the threshold at a test step and is at or
 // below 16 at the end: an orbit grazing |z| = 2 without leaving, one test step in 3 x 10^8 -- is decided
 // exactly by recomputing the orbit from z0 = c with the per-step test (verify_chunk_escape below).
-// 8 instructions per step for the two orbits + 6 per test step: 258 per chunk instead of 420, and no scalar
+// 8 instructions per step for the two orbits + 6 per test step: 258 per 30 steps instead of 420, and no scalar
 // bookkeeping inside the chunk: the executed iterations are counted per chunk (kChunk per orbit that ran it)
 // and the over-count of an orbit's last chunk is taken back when REPLAY knows its escape index
 // (long_overcount).  Only used when every escape inside a full LONG chunk is accepted (min_iter <= the start
