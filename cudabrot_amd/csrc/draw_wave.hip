@@ -206,14 +206,17 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
 
 // ---- HEAD in one piece (head_steps == 4 <= min_iter) -----------------------------------------------
 //
-// Every sample passes through HEAD, so its instruction count is a tenth of the kernel's.  Two asm
-// blocks:
-//   head_draw   four XORWOW outputs (rocrand_xorwow.h:165-177) and the two starting coordinates
+// Every sample passes through HEAD, so its instruction count is a third of the kernel's.  One asm
+// statement (head_loop) runs HEAD passes in a row -- until Q0 holds a MID pass, the input ends or the
+// progress board is due -- so that between two passes nothing but the statement's own scalar
+// bookkeeping is issued (as separate statements per pass the compiler's glue reloaded spilled scalars
+// with nine v_readlane / v_writelane per pass).  A pass is
+//   the draw    four XORWOW outputs (rocrand_xorwow.h:165-177) and the two starting coordinates
 //               (device_math.h, sample_coordinate2), 8 + 5 VALU instructions per output pair half.
 //               The generator's five words rotate by one place per output; instead of moving
-//               registers the block is instantiated for the five rotations (ROT) and the kernel
+//               registers the text is instantiated for the five rotations (ROT) and the kernel
 //               keeps the current rotation in a scalar: logical word j lives in field (j + rot) % 5.
-//   head_test   cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first four
+//   the test    cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first four
 //               iterations under EXEC; the rounded I*I of the tests is the first product of step 1.
 template <int K>
 __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
@@ -274,43 +277,35 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 #define CB_V_KHI "v111"
 #define CB_V_K "v[110:111]"
 #define CB_HEAD_RESERVED CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_D, CB_V_KLO, CB_V_KHI
-__device__ __forceinline__ void head_draw(uint32_t &rot, double &cr, double &ci) {
-  uint32_t t, u, o1, o2, sc, next;
-  double f;
-  asm volatile(
-      "s_cmp_lt_u32 %[rot], 2\n\t"
-      "s_cbranch_scc1 11f\n\t"
-      "s_cmp_eq_u32 %[rot], 2\n\t"
-      "s_cbranch_scc1 12f\n\t"
-      "s_cmp_eq_u32 %[rot], 3\n\t"
-      "s_cbranch_scc1 13f\n\t"
-      CB_HEAD_DRAW(CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3)  // rot 4
-      "s_branch 19f\n\t"
-      "13:\n\t"
-      CB_HEAD_DRAW(CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2)
-      "s_branch 19f\n\t"
-      "12:\n\t"
-      CB_HEAD_DRAW(CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1)
-      "s_branch 19f\n\t"
-      "11:\n\t"
-      "s_cmp_eq_u32 %[rot], 0\n\t"
-      "s_cbranch_scc1 10f\n\t"
-      CB_HEAD_DRAW(CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0)
-      "s_branch 19f\n\t"
-      "10:\n\t"
-      CB_HEAD_DRAW(CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4)
-      "19:\n\t"
-      // four outputs later the words sit four places on: rot <- (rot + 4) % 5
-      "s_add_u32 %[next], %[rot], 4\n\t"
-      "s_sub_u32 %[sc], %[rot], 1\n\t"
-      "s_cmp_ge_u32 %[next], 5\n\t"
-      "s_cselect_b32 %[next], %[sc], %[next]\n\t"
-      : [cr] "=&v"(cr), [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1),
-        [o2] "=&v"(o2), [f] "=&v"(f), [sc] "=&s"(sc), [next] "=&s"(next)
-      : [rot] "s"(__builtin_amdgcn_readfirstlane(rot)), [k2m50] "s"(0x1p-50)
-      : "scc", CB_HEAD_RESERVED);
-  rot = next;
-}
+// The draw of one pass: the text of the five rotations behind scalar branches; it also steps rot
+// (four outputs later the words sit four places on: rot <- (rot + 4) % 5).
+#define CB_HEAD_DRAW_ANY_ROT                                       \
+  "s_cmp_lt_u32 %[rot], 2\n\t"                                     \
+  "s_cbranch_scc1 11f\n\t"                                         \
+  "s_cmp_eq_u32 %[rot], 2\n\t"                                     \
+  "s_cbranch_scc1 12f\n\t"                                         \
+  "s_cmp_eq_u32 %[rot], 3\n\t"                                     \
+  "s_cbranch_scc1 13f\n\t"                                         \
+  CB_HEAD_DRAW(CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3) /* rot 4 */ \
+  "s_branch 19f\n\t"                                               \
+  "13:\n\t"                                                        \
+  CB_HEAD_DRAW(CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1, CB_V_X2)        \
+  "s_branch 19f\n\t"                                               \
+  "12:\n\t"                                                        \
+  CB_HEAD_DRAW(CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0, CB_V_X1)        \
+  "s_branch 19f\n\t"                                               \
+  "11:\n\t"                                                        \
+  "s_cmp_eq_u32 %[rot], 0\n\t"                                     \
+  "s_cbranch_scc1 10f\n\t"                                         \
+  CB_HEAD_DRAW(CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_X0)        \
+  "s_branch 19f\n\t"                                               \
+  "10:\n\t"                                                        \
+  CB_HEAD_DRAW(CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4)        \
+  "19:\n\t"                                                        \
+  "s_add_u32 %[sc], %[rot], 4\n\t"                                 \
+  "s_sub_u32 %[rot], %[rot], 1\n\t"                                \
+  "s_cmp_ge_u32 %[sc], 5\n\t"                                      \
+  "s_cselect_b32 %[rot], %[rot], %[sc]\n\t"
 
 // The reserved registers: load at the start of a launch (logical order, rot = 0) ...
 __device__ __forceinline__ void head_registers_load(const Xorwow &s) {
@@ -355,10 +350,10 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
   return r;
 }
 
-// Cardioid / bulb test and iterations 0..3 of the lanes in `valid`, then the survivors' c goes to Q0
-// (slot (q0_tail + rank) & 127 of the ring at LDS byte address q0_lds: q0_cr there, q0_ci 1024 bytes
-// on).  alive0: lanes outside both regions (cudabrot.cu:398); alive4: lanes that have not escaped
-// after four steps; lane_steps: the iterations the reference executes for these samples up to there.
+// The test of one pass: cardioid / bulb test and iterations 0..3 of the lanes in `valid`, then the
+// survivors' c goes to Q0 (slot (tail + rank) & 127 of the ring at LDS byte address q0_lds: q0_cr there,
+// q0_ci 1024 bytes on).  alive0: lanes outside both regions (cudabrot.cu:398); alive4: lanes that have
+// not escaped after four steps; cnt: the iterations the reference executes for these samples up to there.
 // 0x3fd00000 / 0x40300000: the high words of 0.25 and 16.0 as VOPC literals.
 #define CB_STEP_LIT                                   \
   "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
@@ -370,59 +365,101 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
   "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
-__device__ __forceinline__ void head_test(unsigned long long valid, double cr, double ci,
-                                          uint32_t q0_tail, uint32_t q0_lds,
-                                          unsigned long long &alive0, unsigned long long &alive4,
-                                          uint32_t &lane_steps) {
-  static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci below");
-  unsigned long long save;
-  uint32_t cnt, tmp, slot;
-  double a, r, i, x, q;
+#ifdef CB_BURNING_SHIP
+#define CB_HEAD_SHORTCUT                                                                               \
+  "v_mul_f64 %[a], %[ci], %[ci]\n\t" /* II; no shortcut in this variant (cudabrot.cu:397-399) */      \
+  "s_mov_b64 %[alive0], exec\n\t"
+#else
+#define CB_HEAD_SHORTCUT                                                        \
+  "v_mul_f64 %[a], %[ci], %[ci]\n\t"            /* II */                       \
+  "v_add_f64 %[x], %[cr], -0.5\n\t"             /* X = 2 (re - 1/4) */         \
+  "v_add_f64 %[r], %[cr], 2.0\n\t"              /* T = 2 (re + 1) */           \
+  "v_fma_f64 %[q], %[x], %[x], %[a]\n\t"        /* Q */                        \
+  "v_fma_f64 %[r], %[r], %[r], %[a]\n\t"        /* bulb: fma(T,T,II) */        \
+  "v_fma_f64 %[x], %[x], 2.0, %[q]\n\t"         /* S */                        \
+  "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t" /* !(bulb < 1/4) */            \
+  "v_mul_f64 %[q], %[q], %[x]\n\t"              /* Q * S */                    \
+  "s_mov_b64 %[alive0], vcc\n\t"                                               \
+  "v_cmp_nlt_f64_e64 %[alive4], %[q], %[a]\n\t" /* !(Q*S < II) */              \
+  "s_and_b64 %[alive0], %[alive0], %[alive4]\n\t"
+#endif
+#define CB_HEAD_TEST                                                            \
+  "s_mov_b64 exec, %[valid]\n\t"                                               \
+  CB_HEAD_SHORTCUT                                                              \
+  "s_mov_b64 exec, %[alive0]\n\t"                                              \
+  "s_bcnt1_i32_b64 %[cnt], %[alive0]\n\t"                                      \
+  /* step 1 from z = c; its first product I*I is II */                          \
+  "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"                                    \
+  "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t" \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                                       \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                                             \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                                       \
+  "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"                               \
+  CB_STEP_LIT CB_STEP_LIT CB_STEP_LIT                                           \
+  "s_mov_b64 %[alive4], exec\n\t"                                              \
+  /* survivors (EXEC) -> Q0 */                                                  \
+  "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"                                 \
+  "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"                           \
+  "v_add_u32 %[slot], %[tail], %[slot]\n\t"                                    \
+  "v_and_b32 %[slot], 0x7f, %[slot]\n\t"                                       \
+  "v_lshl_add_u32 %[slot], %[slot], 3, %[lds]\n\t"                             \
+  "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"                      \
+  "s_mov_b64 exec, %[save]\n\t"
+
+// HEAD passes in a row (at least one).  Each takes one sample per lane of `valid` (cudabrot.cu:392-393,
+// 398, 326-337).  The statement stops behind the pass after which
+//   the input has ended (samples_left == 0), or Q0 holds a MID pass (q0_count >= 64), or
+//   the next pass is one the progress board is posted before (samples_left % 32 == 1).
+// q0_tail = q0_head + q0_count on entry (only its low seven bits matter).  The three statistics are added to.
+__device__ __forceinline__ void head_loop(uint32_t &samples_left, uint32_t &rot, unsigned long long valid,
+                                          uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
+                                          uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
+  static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CB_HEAD_TEST");
+  unsigned long long save, alive0, alive4, gone;
+  uint32_t cnt, tmp, sc, slot, t, u, o1, o2;
+  double a, r, i, x, q, f, cr, ci;
+  // wave-uniform by construction; readfirstlane makes that provable where the compiler cannot see it
+  samples_left = __builtin_amdgcn_readfirstlane(samples_left);
+  rot = __builtin_amdgcn_readfirstlane(rot);
+  q0_tail = __builtin_amdgcn_readfirstlane(q0_tail);
+  q0_count = __builtin_amdgcn_readfirstlane(q0_count);
+  n_rejected = __builtin_amdgcn_readfirstlane(n_rejected);
+  n_too_fast = __builtin_amdgcn_readfirstlane(n_too_fast);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
-      "s_mov_b64 exec, %[valid]\n\t"
-#ifdef CB_BURNING_SHIP
-      "v_mul_f64 %[a], %[ci], %[ci]\n\t"             // II; no shortcut in this variant (cudabrot.cu:397-399)
-      "s_mov_b64 %[alive0], exec\n\t"
-#else
-      "v_mul_f64 %[a], %[ci], %[ci]\n\t"             // II
-      "v_add_f64 %[x], %[cr], -0.5\n\t"              // X = 2 (re - 1/4)
-      "v_add_f64 %[r], %[cr], 2.0\n\t"               // T = 2 (re + 1)
-      "v_fma_f64 %[q], %[x], %[x], %[a]\n\t"         // Q
-      "v_fma_f64 %[r], %[r], %[r], %[a]\n\t"         // bulb: fma(T,T,II)
-      "v_fma_f64 %[x], %[x], 2.0, %[q]\n\t"          // S
-      "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t"  // !(bulb < 1/4)
-      "v_mul_f64 %[q], %[q], %[x]\n\t"               // Q * S
-      "s_mov_b64 %[alive0], vcc\n\t"
-      "v_cmp_nlt_f64_e64 %[alive4], %[q], %[a]\n\t"  // !(Q*S < II)
-      "s_and_b64 %[alive0], %[alive0], %[alive4]\n\t"
-#endif
-      "s_mov_b64 exec, %[alive0]\n\t"
-      "s_bcnt1_i32_b64 %[cnt], %[alive0]\n\t"
-      // step 1 from z = c; its first product I*I is II
-      "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
-      "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
-      "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
-      "v_mul_f64 %[a], %[r], %[r]\n\t"
-      "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
-      "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
-      CB_STEP_LIT CB_STEP_LIT CB_STEP_LIT
-      "s_mov_b64 %[alive4], exec\n\t"
-      // survivors (EXEC) -> Q0
-      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
-      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
-      "v_add_u32 %[slot], %[tail], %[slot]\n\t"
-      "v_and_b32 %[slot], 0x7f, %[slot]\n\t"
-      "v_lshl_add_u32 %[slot], %[slot], 3, %[lds]\n\t"
-      "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"
-      "s_mov_b64 exec, %[save]\n\t"
+      "0:\n\t"
+      "s_sub_u32 %[left], %[left], 1\n\t"
+      CB_HEAD_DRAW_ANY_ROT
+      CB_HEAD_TEST
+      // the pass's statistics and the ring
+      "s_andn2_b64 %[valid0], %[valid], %[alive0]\n\t"   // in the cardioid or the bulb
+      "s_bcnt1_i32_b64 %[tmp], %[valid0]\n\t"
+      "s_add_u32 %[rej], %[rej], %[tmp]\n\t"
+      "s_andn2_b64 %[alive0], %[alive0], %[alive4]\n\t"  // escaped within four steps: before min_iter
+      "s_bcnt1_i32_b64 %[tmp], %[alive0]\n\t"
+      "s_add_u32 %[fast], %[fast], %[tmp]\n\t"
+      "s_add_u32 %[steps], %[steps], %[cnt]\n\t"
+      "s_bcnt1_i32_b64 %[tmp], %[alive4]\n\t"
+      "s_add_u32 %[q0c], %[q0c], %[tmp]\n\t"
+      "s_add_u32 %[tail], %[tail], %[tmp]\n\t"
+      // another pass?
+      "s_cmp_eq_u32 %[left], 0\n\t"
+      "s_cbranch_scc1 9f\n\t"
+      "s_cmp_ge_u32 %[q0c], 64\n\t"
+      "s_cbranch_scc1 9f\n\t"
+      "s_and_b32 %[tmp], %[left], 31\n\t"
+      "s_cmp_lg_u32 %[tmp], 1\n\t"
+      "s_cbranch_scc1 0b\n\t"
+      "9:\n\t"
       "s_nop 4\n\t"
-      : [alive0] "=&s"(alive0), [alive4] "=&s"(alive4), [cnt] "=&s"(cnt), [save] "=&s"(save),
-        [tmp] "=&s"(tmp), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x), [q] "=&v"(q),
-        [slot] "=&v"(slot)
-      : [valid] "s"(valid), [cr] "v"(cr), [ci] "v"(ci), [tail] "v"(q0_tail), [lds] "s"(q0_lds)
-      : "vcc", "scc", "memory");
-  lane_steps = cnt;
+      : [left] "+s"(samples_left), [rot] "+s"(rot), [tail] "+s"(q0_tail), [q0c] "+s"(q0_count), [rej] "+s"(n_rejected),
+        [fast] "+s"(n_too_fast), [steps] "+s"(n_steps), [alive0] "=&s"(alive0), [alive4] "=&s"(alive4),
+        [valid0] "=&s"(gone), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [sc] "=&s"(sc),
+        [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x), [q] "=&v"(q), [slot] "=&v"(slot), [cr] "=&v"(cr),
+        [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f)
+      : [valid] "s"(valid), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50)
+      : "vcc", "scc", "memory", CB_HEAD_RESERVED);
 }
 
 // ---- MID in one piece (every escape inside MID is too fast, survivors go on to LONG) ---------------
@@ -1144,12 +1181,12 @@ draw_wave_kernel(DrawArgs a) {
   // wave slot on its SIMD (HW_REG_HW_ID bits 3:0) and chunks done, for the priority rotation
   const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));
   uint32_t long_chunks = 0;
-  // HEAD as one asm block (head_draw / head_test): the usual stage split, where every escape inside
+  // HEAD as one asm block (head_loop): the usual stage split, where every escape inside
   // HEAD is too fast and survivors always have iterations left
   // (launch_draw_wave picks the instance; a kernel holds one of the two HEAD forms so that the
   // generator words have a single user and stay in place)
   constexpr bool fast_head = kFastHead;
-  uint32_t rot = 0;  // rotation of the generator words, see head_draw
+  uint32_t rot = 0;  // rotation of the generator words, see CB_HEAD_DRAW_ANY_ROT
   // LDS byte addresses of this wave's Q0 / Q1 rings (the low half of a flat LDS address is the LDS offset)
   const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
@@ -1408,23 +1445,18 @@ draw_wave_kernel(DrawArgs a) {
     // ---------------------------------------------------------------- HEAD
     if (!feed_input_done && q0_count < 64) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
-      samples_left--;
-      if (((samples_left & 31u) | no_board) == 0u) post_progress_and_set_priority(samples_left);
-      if constexpr (fast_head) {  // the usual split (plan_stages): one asm block each for the draw and the test
-        double c_re, c_im;
-        head_draw(rot, c_re, c_im);  // cudabrot.cu:392-393
-        unsigned long long alive0, alive4;
-        uint32_t steps;
-        head_test(valid_mask, c_re, c_im, (uint32_t) (q0_head + q0_count), q0_lds, alive0, alive4,
-                  steps);  // cudabrot.cu:398, 326-337; survivors -> Q0
-        f_rejected += (uint32_t) __popcll(valid_mask & ~alive0);
-        f_steps += steps;
-        f_too_fast += (uint32_t) __popcll(alive0 & ~alive4);  // escaped before min_iter
-        q0_count += __popcll(alive4);
+      if constexpr (fast_head) {  // the usual split (plan_stages): HEAD passes in a row as one asm statement
+        if ((((samples_left - 1u) & 31u) | no_board) == 0u) post_progress_and_set_priority(samples_left - 1u);
+        uint32_t count = (uint32_t) q0_count;
+        head_loop(samples_left, rot, valid_mask, (uint32_t) (q0_head + q0_count), count, q0_lds, f_rejected,
+                  f_too_fast, f_steps);  // survivors -> Q0
+        q0_count = (int) count;
         if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
         if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
         continue;
       }
+      samples_left--;
+      if (((samples_left & 31u) | no_board) == 0u) post_progress_and_set_priority(samples_left);
       bool alive = false;
       Orbit o = {0, 0, 0, 0};
       if (valid) {
