@@ -67,6 +67,25 @@ constexpr int kOrbitsPerLane = 2;      // deep orbits a lane iterates side by si
 constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
 constexpr int kQ1Cap = 96;             // MID survivors: (c, z)        (3 KiB per wave)
 constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB per wave)
+// Iterations of the HEAD stage (every lane, one sample each), 2..4.  After the shortcut test and k iterations
+// 30.5 / 17.3 / 11.9 / 8.9 % of the samples are still iterating (k = 1..4): HEAD's later steps run with most
+// lanes switched off, MID's re-derive them for the survivors only.
+#ifndef CB_HEAD_STEPS
+#define CB_HEAD_STEPS 4
+#endif
+#if CB_HEAD_STEPS == 4
+#define CB_HEAD_MORE_STEPS CB_STEP_LIT CB_STEP_LIT CB_STEP_LIT
+#define CB_MID_REDERIVE_MORE CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
+#elif CB_HEAD_STEPS == 3
+#define CB_HEAD_MORE_STEPS CB_STEP_LIT CB_STEP_LIT
+#define CB_MID_REDERIVE_MORE CB_STEP_NOTEST CB_STEP_NOTEST
+#elif CB_HEAD_STEPS == 2
+#define CB_HEAD_MORE_STEPS CB_STEP_LIT
+#define CB_MID_REDERIVE_MORE CB_STEP_NOTEST
+#else
+#error "CB_HEAD_STEPS: 2, 3 or 4"
+#endif
+constexpr int kHeadSteps = CB_HEAD_STEPS;
 #ifndef CB_Q1_LOW
 #define CB_Q1_LOW 32
 #endif
@@ -204,7 +223,7 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
   return accepted;
 }
 
-// ---- HEAD in one piece (head_steps == 4 <= min_iter) -----------------------------------------------
+// ---- HEAD in one piece (head_steps == kHeadSteps <= min_iter) -----------------------------------------------
 //
 // Every sample passes through HEAD, so its instruction count is a third of the kernel's.  One asm
 // statement (head_loop) runs HEAD passes in a row -- until Q0 holds a MID pass, the input ends or the
@@ -216,7 +235,7 @@ __device__ __forceinline__ unsigned long long iterate_window(unsigned long long 
 //               The generator's five words rotate by one place per output; instead of moving
 //               registers the text is instantiated for the five rotations (ROT) and the kernel
 //               keeps the current rotation in a scalar: logical word j lives in field (j + rot) % 5.
-//   the test    cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first four
+//   the test    cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first kHeadSteps
 //               iterations under EXEC; the rounded I*I of the tests is the first product of step 1.
 template <int K>
 __device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
@@ -350,10 +369,10 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
   return r;
 }
 
-// The test of one pass: cardioid / bulb test and iterations 0..3 of the lanes in `valid`, then the
+// The test of one pass: cardioid / bulb test and HEAD's iterations of the lanes in `valid`, then the
 // survivors' c goes to Q0 (slot (tail + rank) & 127 of the ring at LDS byte address q0_lds: q0_cr there,
 // q0_ci 1024 bytes on).  alive0: lanes outside both regions (cudabrot.cu:398); alive4: lanes that have
-// not escaped after four steps; cnt: the iterations the reference executes for these samples up to there.
+// not escaped after HEAD's steps; cnt: the iterations the reference executes for these samples up to there.
 // 0x3fd00000 / 0x40300000: the high words of 0.25 and 16.0 as VOPC literals.
 #define CB_STEP_LIT                                   \
   "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
@@ -395,7 +414,7 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
   "v_mul_f64 %[a], %[r], %[r]\n\t"                                             \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                                       \
   "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"                               \
-  CB_STEP_LIT CB_STEP_LIT CB_STEP_LIT                                           \
+  CB_HEAD_MORE_STEPS                                                            \
   "s_mov_b64 %[alive4], exec\n\t"                                              \
   /* survivors (EXEC) -> Q0 */                                                  \
   "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"                                 \
@@ -436,7 +455,7 @@ __device__ __forceinline__ void head_loop(uint32_t &samples_left, uint32_t &rot,
       "s_andn2_b64 %[valid0], %[valid], %[alive0]\n\t"   // in the cardioid or the bulb
       "s_bcnt1_i32_b64 %[tmp], %[valid0]\n\t"
       "s_add_u32 %[rej], %[rej], %[tmp]\n\t"
-      "s_andn2_b64 %[alive0], %[alive0], %[alive4]\n\t"  // escaped within four steps: before min_iter
+      "s_andn2_b64 %[alive0], %[alive0], %[alive4]\n\t"  // escaped in HEAD: before min_iter
       "s_bcnt1_i32_b64 %[tmp], %[alive0]\n\t"
       "s_add_u32 %[fast], %[fast], %[tmp]\n\t"
       "s_add_u32 %[steps], %[steps], %[cnt]\n\t"
@@ -465,7 +484,7 @@ __device__ __forceinline__ void head_loop(uint32_t &samples_left, uint32_t &rot,
 // ---- MID in one piece (every escape inside MID is too fast, survivors go on to LONG) ---------------
 //
 // The lanes of `take` pop c from Q0 (ring slot (q0_head + lane) & 127 at LDS byte address q0_lds),
-// re-derive z after the four HEAD iterations (Q0 keeps only c; no escape is possible there, so no
+// re-derive z after the HEAD iterations (Q0 keeps only c; no escape is possible there, so no
 // compare), run n_steps more iterations under EXEC and push the survivors' (c, z) to Q1 (ring slot
 // (q1_tail + rank) mod 96 at q1_lds; q1_ci, q1_r, q1_i follow at 768-byte distances).  lane_steps:
 // the executed iterations of the n_steps window; alive: the survivors.
@@ -492,12 +511,12 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_mov_b32 %[cnt], 0\n\t"
       "s_mov_b32 %[ctr], %[n]\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
-      // iterations 0..3 again, from z = c (first product: I*I with I = ci)
+      // HEAD's iterations again, from z = c (first product: I*I with I = ci)
       "v_mul_f64 %[a], %[ci], %[ci]\n\t"
       "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
       "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
       "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
-      CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
+      CB_MID_REDERIVE_MORE
       "s_cmp_eq_u32 %[n], 0\n\t"
       "s_cbranch_scc1 2f\n\t"
       "1:\n\t"
@@ -577,12 +596,16 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
 #define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
 #elif CB_CHUNK == 60
 #define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4
+#elif CB_CHUNK == 90
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X24 CB_STEP2X24 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2X4 CB_STEP2 CB_STEP2
+#elif CB_CHUNK == 120
+#define CB_STEP2_CHUNK CB_STEP2X24 CB_STEP2X24 CB_STEP2X24 CB_STEP2X24 CB_STEP2X24
 #else
 #error "unroll CB_STEP2 for this chunk length"
 #endif
 #define CB_STR2(x) #x
 #define CB_STR(x) CB_STR2(x)
-#define CB_CHUNK_S CB_STR(CB_CHUNK)  // the chunk length as an inline constant of the asm blocks below
+#define CB_CHUNK_S CB_STR(CB_CHUNK)  // the chunk length as a constant of the asm blocks below (VOP2 / VOPC e32: may be a literal)
 
 // kChunk steps on orbit A of the lanes in mask_a and on orbit B of the lanes in mask_b (both
 // wave-uniform; called with EXEC = all 64 lanes).  esc_a / esc_b receive the lanes whose orbit
@@ -673,6 +696,12 @@ constexpr int kSparseStride = 10;  // steps between tests; the bound above is fo
 #define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
 #elif CB_CHUNK == 40
 #define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#elif CB_CHUNK == 90
+#define CB_SPARSE_GROUP_NEXT3 CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT3 CB_SPARSE_GROUP_NEXT3
+#elif CB_CHUNK == 120
+#define CB_SPARSE_GROUP_NEXT3 CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT
+#define CB_SPARSE_CHUNK CB_SPARSE_GROUP_FIRST CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT CB_SPARSE_GROUP_NEXT3 CB_SPARSE_GROUP_NEXT3 CB_SPARSE_GROUP_NEXT3
 #else
 #define CB_SPARSE_CHUNK
 #endif
@@ -752,7 +781,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
                                             uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
                                             uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
                                             unsigned long long &full, unsigned long long &tail) {
-  static_assert(kQ1Cap == 96 && kChunk <= 64, "ring length and plane distances below; chunk length as an inline constant");
+  static_assert(kQ1Cap == 96, "ring length and plane distances below");
   unsigned long long save;
   uint32_t n, rank, slot, t;
   asm volatile(
@@ -779,8 +808,9 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "v_mov_b32 %[lrem], %[ls]\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "1:\n\t"
-      "v_cmp_le_u32_e64 %[full], " CB_CHUNK_S ", %[lrem]\n\t"
+      "v_cmp_le_u32_e32 vcc, " CB_CHUNK_S ", %[lrem]\n\t"   // (e32: the chunk length may be a literal)
       "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
+      "s_mov_b64 %[full], vcc\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
       : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
         [lrem] "+v"(l_rem), [n] "=&s"(n), [full] "=&s"(full), [tail] "=&s"(tail), [save] "=&s"(save),
@@ -865,7 +895,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
                                             uint32_t check_periodic, uint32_t q2_tail, uint32_t q2_lds,
                                             unsigned long long &push, unsigned long long &ended,
                                             unsigned long long &periodic) {
-  static_assert(kQ2Cap == 192 && kChunk <= 64, "ring length and plane distance below; chunk length as an inline constant");
+  static_assert(kQ2Cap == 192, "ring length and plane distance below");
   static_assert(kBrentBits >= 1 && kBrentBits <= 8, "bits of the chunk count kept by the save schedule");
   unsigned long long save;
   uint32_t slot, t;
@@ -1504,7 +1534,7 @@ draw_wave_kernel(DrawArgs a) {
     if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
       const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
       const int n = q0_count < 64 ? q0_count : 64;
-      // MID as one asm block (mid_pass) under the usual split: HEAD did four iterations, every escape inside
+      // MID as one asm block (mid_pass) under the usual split: HEAD did kHeadSteps iterations, every escape inside
       // MID is too fast (the stage ends at or before min_iter) and survivors have iterations left
       const KernelArgs ma = fresh_args();
       if (kFastHead && ma->fast_mid) {
@@ -1801,7 +1831,7 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   if (binned && a.bin.n_waves != blocks * kWavesPerBlock) return hipErrorInvalidValue;
   // HEAD as one asm block needs the usual stage split: every escape inside HEAD is too fast and
   // survivors always have iterations left
-  const bool fast = (a.head_steps == 4) && (a.min_iter >= 4) && (a.max_iter > 4);
+  const bool fast = (a.head_steps == kHeadSteps) && (a.min_iter >= kHeadSteps) && (a.max_iter > kHeadSteps);
   const dim3 grid(blocks), block(threads);
   // the level-A counts of the two-level sort made in the REPLAY burst (the product instances only)
   const bool count = binned && !timed && a.bin.count_in_draw != 0u;
@@ -1832,7 +1862,7 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
 // kChunk.  mid is chosen so that min_iter - (head + mid) is a multiple of kChunk whenever min_iter
 // lies beyond the MID stage: then no LONG chunk straddles min_iter.
 void plan_stages(int max_iter, int min_iter, int *head_steps, int *mid_steps) {
-  const int kHead = 4, kMidMin = 12;
+  const int kHead = kHeadSteps, kMidMin = 12;
   int head = kHead;
   if (max_iter < head) head = max_iter < 0 ? 0 : max_iter;
   int rem = max_iter - head;
