@@ -86,6 +86,13 @@ constexpr int kQ2Cap = 192;            // accepted starting points: c  (3 KiB pe
 #error "CB_HEAD_STEPS: 2, 3 or 4"
 #endif
 constexpr int kHeadSteps = CB_HEAD_STEPS;
+// -DCB_DBG_REPLAY: the timed kernel's wave dump counts REPLAY burst steps and the lanes active in them
+// (tools/wave_dump_stats.py prints them as "chunks" and "slots") instead of LONG chunks and orbit slots.
+#ifdef CB_DBG_REPLAY
+constexpr bool kDbgReplay = true;
+#else
+constexpr bool kDbgReplay = false;
+#endif
 #ifndef CB_Q1_LOW
 #define CB_Q1_LOW 32
 #endif
@@ -1060,7 +1067,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                                              int &p_steps, const Canvas &cv, uint32_t *region,
                                              uint32_t &fill, uint32_t &lane_steps, uint32_t &hits,
                                              uint32_t row_shift, uint32_t tag,
-                                             unsigned long long emit, uint32_t group_counts_lds) {
+                                             unsigned long long emit, uint32_t group_counts_lds,
+                                             uint32_t *burst_steps = nullptr) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
@@ -1151,6 +1159,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   }
   lane_steps = cs;
   hits = ch;
+  // (diagnostics) steps of this burst: the loop leaves before its counter steps when the last lane ends
+  if (burst_steps) *burst_steps = n_steps - ctr + (act == 0ull ? 1u : 0u);
 }
 
 // ring index helpers for the 96-entry Q1 and the 192-entry Q2
@@ -1389,13 +1399,17 @@ draw_wave_kernel(DrawArgs a) {
           unsigned long long act_mask = __ballot(p_act);
           const unsigned long long was_act = act_mask;
           const unsigned long long emit = multi ? __ballot(p_real) : ~0ull;
-          uint32_t steps = 0, hits = 0;
+          uint32_t steps = 0, hits = 0, burst = 0;
           if (cv.pow2_real && cv.pow2_imag) {
             replay_burst<true, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds);
+                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds, kDbgReplay ? &burst : nullptr);
           } else {
             replay_burst<false, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds);
+                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds, kDbgReplay ? &burst : nullptr);
+          }
+          if (kTimed && kDbgReplay) {  // the wave dump then describes REPLAY bursts instead of LONG chunks
+            dbg_chunks += burst;
+            dbg_slots += steps;
           }
           n_replay += steps;
           n_incr += hits;
@@ -1689,7 +1703,7 @@ draw_wave_kernel(DrawArgs a) {
           iterate_chunk2(full_mask[0], full_mask[1], lo[0], lo[1], esc[0], esc[1], steps);
           n_iterate += steps;
         }
-        if (kTimed) {
+        if (kTimed && !kDbgReplay) {
           dbg_chunks++;
           dbg_slots += (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]));
         }
