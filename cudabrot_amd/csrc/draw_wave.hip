@@ -287,22 +287,19 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
                   4u * 362437u == 0x161f14u,
               "multiples of the Weyl increment (rocrand_xorwow.h:174)");
 
-// rot: logical word j lives in register v[120 + (j + rot) % 5].  In the kernels that use this block
-// the generator lives in v104..v109 (five words and the Weyl value) and v[110:111] holds the constant
-// 2^-50 - 4 for the whole launch: the kernel is compiled with a budget of 104 vector registers
-// (amdgpu_num_vgpr), so the compiler never touches them, and no copy in or out of the block is
-// needed (as operands the six words were copied to fresh registers and back on every pass).
+// rot: logical word j lives in field (j + rot) % 5 of the generator (operands x0..x4; xd: the Weyl value;
+// kk: the constant 2^-50 - 4 in a vector pair).  The six words are operands of head_loop, which runs several
+// passes per statement, so the compiler knows they are live and any copies it makes are per statement, not per
+// pass.  (They used to sit in v104..v109 behind a register budget -- amdgpu_num_vgpr(104) -- that the
+// compiler turned out to be free to exceed: with a little more pressure it used those registers itself.)
 // One statement holds the text for the five rotations behind scalar branches; it also steps rot.
-#define CB_V_X0 "v104"
-#define CB_V_X1 "v105"
-#define CB_V_X2 "v106"
-#define CB_V_X3 "v107"
-#define CB_V_X4 "v108"
-#define CB_V_D "v109"
-#define CB_V_KLO "v110"
-#define CB_V_KHI "v111"
-#define CB_V_K "v[110:111]"
-#define CB_HEAD_RESERVED CB_V_X0, CB_V_X1, CB_V_X2, CB_V_X3, CB_V_X4, CB_V_D, CB_V_KLO, CB_V_KHI
+#define CB_V_X0 "%[x0]"
+#define CB_V_X1 "%[x1]"
+#define CB_V_X2 "%[x2]"
+#define CB_V_X3 "%[x3]"
+#define CB_V_X4 "%[x4]"
+#define CB_V_D "%[xd]"
+#define CB_V_K "%[kk]"
 // The draw of one pass: the text of the five rotations behind scalar branches; it also steps rot
 // (four outputs later the words sit four places on: rot <- (rot + 4) % 5).
 #define CB_HEAD_DRAW_ANY_ROT                                       \
@@ -332,36 +329,6 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
   "s_sub_u32 %[rot], %[rot], 1\n\t"                                \
   "s_cmp_ge_u32 %[sc], 5\n\t"                                      \
   "s_cselect_b32 %[rot], %[rot], %[sc]\n\t"
-
-// The reserved registers: load at the start of a launch (logical order, rot = 0) ...
-__device__ __forceinline__ void head_registers_load(const Xorwow &s) {
-  asm volatile(
-      "v_mov_b32 " CB_V_X0 ", %[x0]\n\t"
-      "v_mov_b32 " CB_V_X1 ", %[x1]\n\t"
-      "v_mov_b32 " CB_V_X2 ", %[x2]\n\t"
-      "v_mov_b32 " CB_V_X3 ", %[x3]\n\t"
-      "v_mov_b32 " CB_V_X4 ", %[x4]\n\t"
-      "v_mov_b32 " CB_V_D ", %[d]\n\t"
-      "v_mov_b32 " CB_V_KLO ", 0xfffffffe\n\t"  // 2^-50 - 4 = 0xc00fffff'fffffffe
-      "v_mov_b32 " CB_V_KHI ", 0xc00fffff\n\t"
-      :
-      : [x0] "v"(s.x0), [x1] "v"(s.x1), [x2] "v"(s.x2), [x3] "v"(s.x3), [x4] "v"(s.x4), [d] "v"(s.d)
-      : CB_HEAD_RESERVED);
-}
-// ... and read back at its end (fields as the registers hold them: logical word j in field (j + rot) % 5).
-__device__ __forceinline__ Xorwow head_registers_read() {
-  Xorwow s;
-  asm volatile(
-      "v_mov_b32 %[x0], " CB_V_X0 "\n\t"
-      "v_mov_b32 %[x1], " CB_V_X1 "\n\t"
-      "v_mov_b32 %[x2], " CB_V_X2 "\n\t"
-      "v_mov_b32 %[x3], " CB_V_X3 "\n\t"
-      "v_mov_b32 %[x4], " CB_V_X4 "\n\t"
-      "v_mov_b32 %[d], " CB_V_D "\n\t"
-      : [x0] "=v"(s.x0), [x1] "=v"(s.x1), [x2] "=v"(s.x2), [x3] "=v"(s.x3), [x4] "=v"(s.x4),
-        [d] "=v"(s.d));
-  return s;
-}
 
 // The generator words in logical order again (rot back to 0), for store_rng and the generic HEAD.
 template <int ROT>
@@ -437,7 +404,7 @@ __device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {
 //   the input has ended (samples_left == 0), or Q0 holds a MID pass (q0_count >= 64), or
 //   the next pass is one the progress board is posted before (samples_left % 32 == 1).
 // q0_tail = q0_head + q0_count on entry (only its low seven bits matter).  The three statistics are added to.
-__device__ __forceinline__ void head_loop(uint32_t &samples_left, uint32_t &rot, unsigned long long valid,
+__device__ __forceinline__ void head_loop(Xorwow &g, uint32_t &samples_left, uint32_t &rot, unsigned long long valid,
                                           uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
                                           uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
   static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CB_HEAD_TEST");
@@ -483,9 +450,10 @@ __device__ __forceinline__ void head_loop(uint32_t &samples_left, uint32_t &rot,
         [fast] "+s"(n_too_fast), [steps] "+s"(n_steps), [alive0] "=&s"(alive0), [alive4] "=&s"(alive4),
         [valid0] "=&s"(gone), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [sc] "=&s"(sc),
         [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x), [q] "=&v"(q), [slot] "=&v"(slot), [cr] "=&v"(cr),
-        [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f)
-      : [valid] "s"(valid), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50)
-      : "vcc", "scc", "memory", CB_HEAD_RESERVED);
+        [ci] "=&v"(ci), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
+        [x0] "+v"(g.x0), [x1] "+v"(g.x1), [x2] "+v"(g.x2), [x3] "+v"(g.x3), [x4] "+v"(g.x4), [xd] "+v"(g.d)
+      : [valid] "s"(valid), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50), [kk] "v"(0x1p-50 - 4.0)
+      : "vcc", "scc", "memory");
 }
 
 // ---- MID in one piece (every escape inside MID is too fast, survivors go on to LONG) ---------------
@@ -1003,7 +971,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
   "v_cmp_le_f64_e64 %[hx], %[minx2], %[r]\n\t"            \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
-#define CB_REPLAY_TAIL                                    \
+// ..._TAGGED: fused channels (the word carries the channel's tag, lanes still measuring do not write);
+// ..._PLAIN: one channel -- no tag, every lane of the step writes.
+#define CB_REPLAY_TAIL_TAGGED                                  \
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
@@ -1015,6 +985,22 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "s_and_b64 vcc, vcc, %[emit]\n\t"                       \
+  "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
+  "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"
+#define CB_REPLAY_TAIL_PLAIN                                   \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
+  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
   "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
   "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
@@ -1068,7 +1054,7 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                                              uint32_t &fill, uint32_t &lane_steps, uint32_t &hits,
                                              uint32_t row_shift, uint32_t tag,
                                              unsigned long long emit, uint32_t group_counts_lds,
-                                             uint32_t *burst_steps = nullptr) {
+                                             bool tagged, uint32_t *burst_steps = nullptr) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
@@ -1093,7 +1079,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   if (kPow2 && kCount) {
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL CB_REPLAY_COUNT CB_REPLAY_TAIL2
+    if (tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_TAGGED CB_REPLAY_COUNT CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
@@ -1104,12 +1091,26 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
                  : "vcc", "scc", "memory");
+    } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_PLAIN CB_REPLAY_COUNT CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
+                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
+                 : "vcc", "scc", "memory");
+    }
   } else if (kCount) {
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL CB_REPLAY_COUNT CB_REPLAY_TAIL2
+    if (tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_TAGGED CB_REPLAY_COUNT CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
@@ -1122,12 +1123,28 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
                  : "vcc", "scc", "memory");
+    } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_PLAIN CB_REPLAY_COUNT CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
+                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
+                 : "vcc", "scc", "memory");
+    }
   } else if (kPow2) {
     // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
     // a VALU instruction reads one scalar operand
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL CB_REPLAY_TAIL2
+    if (tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_TAGGED CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
@@ -1138,12 +1155,26 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
+    } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_PLAIN CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
+                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit)
+                 : "vcc", "scc", "memory");
+    }
   } else {
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
     const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL CB_REPLAY_TAIL2
+    if (tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_TAGGED CB_REPLAY_TAIL2
                  : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
                    [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
                    [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
@@ -1156,6 +1187,21 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
+    } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_PLAIN CB_REPLAY_TAIL2
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
+                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
+                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
+                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
+                   [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
+                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
+                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [tag] "v"(tag), [emit] "s"(emit)
+                 : "vcc", "scc", "memory");
+    }
   }
   lane_steps = cs;
   hits = ch;
@@ -1169,7 +1215,7 @@ __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot 
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
 template <bool kTimed, bool kBinned, bool kFastHead, bool kCount>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_num_vgpr(104)))
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // four waves per SIMD: at most 128 vector registers
 draw_wave_kernel(DrawArgs a) {
   static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
   static_assert(!kCount || kBinned, "the level-A counts are counts of stream words");
@@ -1205,7 +1251,6 @@ draw_wave_kernel(DrawArgs a) {
 
   Xorwow rng = {0, 0, 0, 0, 0, 0};
   if (valid) rng = load_rng(a.states, a.n_threads, tid);
-  if constexpr (kFastHead) head_registers_load(rng);  // the generator lives in v104..v109 from here on
 
   // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t samples_left = a.samples_per_thread;
@@ -1402,10 +1447,10 @@ draw_wave_kernel(DrawArgs a) {
           uint32_t steps = 0, hits = 0, burst = 0;
           if (cv.pow2_real && cv.pow2_imag) {
             replay_burst<true, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds, kDbgReplay ? &burst : nullptr);
+                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds, multi, kDbgReplay ? &burst : nullptr);
           } else {
             replay_burst<false, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds, kDbgReplay ? &burst : nullptr);
+                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds, multi, kDbgReplay ? &burst : nullptr);
           }
           if (kTimed && kDbgReplay) {  // the wave dump then describes REPLAY bursts instead of LONG chunks
             dbg_chunks += burst;
@@ -1492,7 +1537,7 @@ draw_wave_kernel(DrawArgs a) {
       if constexpr (fast_head) {  // the usual split (plan_stages): HEAD passes in a row as one asm statement
         if ((((samples_left - 1u) & 31u) | no_board) == 0u) post_progress_and_set_priority(samples_left - 1u);
         uint32_t count = (uint32_t) q0_count;
-        head_loop(samples_left, rot, valid_mask, (uint32_t) (q0_head + q0_count), count, q0_lds, f_rejected,
+        head_loop(rng, samples_left, rot, valid_mask, (uint32_t) (q0_head + q0_count), count, q0_lds, f_rejected,
                   f_too_fast, f_steps);  // survivors -> Q0
         q0_count = (int) count;
         if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
@@ -1744,7 +1789,6 @@ draw_wave_kernel(DrawArgs a) {
   if (board_row && lane_id() == 0) {  // this wave no longer competes
     __hip_atomic_store(board_row + (wave_slot & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if constexpr (kFastHead) rng = head_registers_read();
   switch (rot) {  // back to the logical order of the generator words
     case 1: rng = xorwow_unrotated<1>(rng); break;
     case 2: rng = xorwow_unrotated<2>(rng); break;
