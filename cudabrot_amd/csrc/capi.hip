@@ -133,7 +133,6 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
 int empty_stream_if_nothing_launches(const cb::DrawArgs &a, hipStream_t stream) {
   const bool launches = a.n_threads != 0 && (a.samples_per_thread != 0 || (a.carry != nullptr && a.drain != 0));
   if (launches || !a.bin.enabled) return 0;
-  CB_TRY(hipMemsetAsync(a.bin.draw_counted, 0, sizeof(uint32_t), stream));  // nobody counted: group_count_kernel will
   return (int) hipMemsetAsync(a.bin.wave_count, 0, (size_t) a.bin.n_waves * sizeof(uint32_t), stream);
 }
 

@@ -1007,22 +1007,57 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
   "s_mov_b64 exec, vcc\n\t"                               \
   "global_store_dword %[pidx], %[e], %[base]\n\t"
-// kCount (canvases beyond 1024 tiles, BinLayout::count_in_draw): the level-A counts of the two-level sort are
-// made here, where every stream word is born, instead of by a pass over the stream (scatter.hip, group_count):
-// key = (tile >> 10) * 4 + (index of the word in the wave's segment & 3), one ds_add per word into the wave's
-// counters.  EXEC = the lanes that stored a word; row and col are free once the word is formed.
-#define CB_REPLAY_COUNT                                   \
+// kChunked (canvases beyond 1024 tiles, BinLayout::chunked): the word goes to the current chunk of its GROUP of
+// 1024 tiles instead of the end of the wave's segment.  EXEC = the lanes with a word (vcc of the tail above).
+// group = tile >> 10; the group's {next word, end of chunk} (indices into the wave's segment) sit in the wave's
+// LDS at gcl + 8 * group: one returning add takes the place, lanes that find it behind the end of the chunk
+// (`over`) keep their word in e -- the burst then ends with this step and the caller opens new chunks for them
+// (replay_burst_chunked).  row and col are free once the word is formed.
+#define CB_REPLAY_CHUNKED                                 \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "s_mov_b64 exec, vcc\n\t"                               \
   "v_lshrrev_b32 %[pl], %[chs], %[tag]\n\t"               \
   "v_lshrrev_b32 %[row], 7, %[row]\n\t"                   \
   "v_lshrrev_b32 %[col], 7, %[col]\n\t"                   \
   "v_mad_u32_u24 %[row], %[pl], %[tly], %[row]\n\t"       \
   "v_mad_u32_u24 %[row], %[row], %[tlx], %[col]\n\t"      \
-  "v_bfe_u32 %[col], %[pidx], 2, 2\n\t"                   \
-  "v_lshrrev_b32 %[row], 10, %[row]\n\t"                  \
-  "v_lshl_or_b32 %[row], %[row], 2, %[col]\n\t"           \
-  "v_mov_b32 %[col], 1\n\t"                               \
-  "v_lshl_add_u32 %[row], %[row], 2, %[gcl]\n\t"          \
-  "ds_add_u32 %[row], %[col]\n\t"
+  "v_lshrrev_b32 %[grp], 10, %[row]\n\t"                  \
+  "v_lshl_add_u32 %[col], %[grp], 3, %[gcl]\n\t"          \
+  "ds_add_rtn_u32 %[pos], %[col], %[one]\n\t"             \
+  "ds_read_b32 %[lim], %[col] offset:4\n\t"               \
+  "s_waitcnt lgkmcnt(0)\n\t"                              \
+  "v_cmp_lt_u32_e32 vcc, %[pos], %[lim]\n\t"              \
+  "s_andn2_b64 %[over], exec, vcc\n\t"                    \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "v_lshlrev_b32 %[pidx], 2, %[pos]\n\t"                  \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"
+// the tail of the tagged form up to the hit mask (no compaction: the place comes from the group's cursor)
+#define CB_REPLAY_TAIL_HITS                               \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
+  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "s_and_b64 vcc, vcc, %[emit]\n\t"
+#define CB_REPLAY_TAIL2_CHUNKED                           \
+  "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_cmp_lg_u64 %[over], 0\n\t"                           \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_cmp_eq_u64 %[act], 0\n\t"                            \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
+  "s_cbranch_scc1 1b\n\t"                                 \
+  "2:\n\t"                                                \
+  "s_mov_b64 exec, %[save]\n\t"                           \
+  "s_nop 4\n\t"
 #define CB_REPLAY_TAIL2                                   \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
@@ -1048,17 +1083,17 @@ __device__ __forceinline__ KernelArgs fresh_args() {
   return p;
 }
 
-template <bool kPow2, bool kCount>
+template <bool kPow2>
 __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                              int &p_steps, const Canvas &cv, uint32_t *region,
                                              uint32_t &fill, uint32_t &lane_steps, uint32_t &hits,
                                              uint32_t row_shift, uint32_t tag,
-                                             unsigned long long emit, uint32_t group_counts_lds,
-                                             bool tagged, uint32_t *burst_steps = nullptr) {
+                                             unsigned long long emit, bool tagged,
+                                             uint32_t *burst_steps = nullptr) {
   unsigned long long save, alive, hx, hy, scp;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
-  uint32_t col, row, pidx, e, pl;
+  uint32_t col, row, pidx, e;
   // All "s" operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
   (void) cv;
   const KernelArgs ka = fresh_args();
@@ -1071,74 +1106,7 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   row_shift = __builtin_amdgcn_readfirstlane(row_shift);
   emit = uniform_u64(emit);
   const double k16 = 16.0;
-  // kCount: the layout of the tile grid (scalar loads like the rest) and the wave's counters in LDS
-  const uint32_t tlx = kCount ? ka->bin.tiles_x : 0u, tly = kCount ? ka->bin.tiles_y : 0u;
-  const uint32_t chs = kCount ? ka->bin.e_chan_shift : 0u;
-  group_counts_lds = __builtin_amdgcn_readfirstlane(group_counts_lds);
-#define CB_REPLAY_COUNT_OPERANDS , [tlx] "s"(tlx), [tly] "s"(tly), [chs] "s"(chs), [gcl] "s"(group_counts_lds)
-  if (kPow2 && kCount) {
-    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
-    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
-    if (tagged) {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_TAGGED CB_REPLAY_COUNT CB_REPLAY_TAIL2
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
-                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
-                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
-                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
-                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
-                 : "vcc", "scc", "memory");
-    } else {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_PLAIN CB_REPLAY_COUNT CB_REPLAY_TAIL2
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
-                   [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
-                   [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
-                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
-                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
-                 : "vcc", "scc", "memory");
-    }
-  } else if (kCount) {
-    const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
-    const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
-    const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
-    const double kg = 0.5 - 0x1p-24;
-    if (tagged) {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_TAGGED CB_REPLAY_COUNT CB_REPLAY_TAIL2
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
-                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
-                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
-                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
-                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
-                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
-                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
-                 : "vcc", "scc", "memory");
-    } else {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_PLAIN CB_REPLAY_COUNT CB_REPLAY_TAIL2
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy),
-                   [scp] "=&s"(scp), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t),
-                   [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
-                   [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
-                   [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
-                   [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
-                   [tag] "v"(tag), [emit] "s"(emit) CB_REPLAY_COUNT_OPERANDS
-                 : "vcc", "scc", "memory");
-    }
-  } else if (kPow2) {
+  if (kPow2) {
     // fx = fma(R, 0.5/d, -min/d): scale in a scalar pair, offset in a (wave-constant) vector pair --
     // a VALU instruction reads one scalar operand
     const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
@@ -1209,26 +1177,122 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   if (burst_steps) *burst_steps = n_steps - ctr + (act == 0ull ? 1u : 0u);
 }
 
+
+// The same burst on a CHUNKED stream (BinLayout::chunked, CB_REPLAY_CHUNKED): every word goes to the current chunk
+// of its group.  cursors / cursors_lds: the wave's {next word, end of chunk} pairs in LDS and their LDS byte
+// address; next_chunk: the
+// first chunk of the wave's segment that is still free (the caller has made sure that a burst cannot run out:
+// it opens at most one chunk per group and one per kChunkWords words); desc: the wave's row of chunk_desc.
+template <bool kPow2>
+__device__ __forceinline__ void replay_burst_chunked(unsigned long long &act, uint32_t n_steps, Orbit &p,
+                                                     int &p_steps, uint32_t *region, uint32_t &fill,
+                                                     uint32_t &lane_steps, uint32_t &hits, uint32_t row_shift,
+                                                     uint32_t tag, unsigned long long emit, uint32_t *cursors,
+                                                     uint32_t cursors_lds, uint32_t &next_chunk, uint32_t *desc,
+                                                     uint32_t *burst_steps = nullptr) {
+  unsigned long long save, alive, hx, hy, scp, over;
+  uint32_t cs, ch, ctr, t;
+  double a, fx, fy, d0, d1, d2, d3;
+  uint32_t col, row, pidx, e, pl, grp, pos, lim;
+  const KernelArgs ka = fresh_args();
+  const double minx2 = ka->replay_min2_real, miny2 = ka->replay_min2_imag;
+  const uint32_t w = (uint32_t) ka->w, h = (uint32_t) ka->h;
+  region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
+  act = uniform_u64(act);
+  fill = __builtin_amdgcn_readfirstlane(fill);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  row_shift = __builtin_amdgcn_readfirstlane(row_shift);
+  emit = uniform_u64(emit);
+  cursors_lds = __builtin_amdgcn_readfirstlane(cursors_lds);
+  const double k16 = 16.0;
+  const uint32_t tlx = ka->bin.tiles_x, tly = ka->bin.tiles_y, chs = ka->bin.e_chan_shift;
+  const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+  const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+#define CB_CHUNKED_OUTPUTS                                                                                       \
+  [r] "+v"(p.r), [i] "+v"(p.i), [ps] "+v"(p_steps), [act] "+s"(act), [fill] "+s"(fill), [save] "=&s"(save),      \
+      [alive] "=&s"(alive), [hx] "=&s"(hx), [hy] "=&s"(hy), [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr),    \
+      [t] "=&s"(t), [over] "=&s"(over), [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col),          \
+      [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl), [grp] "=&v"(grp), [pos] "=&v"(pos),    \
+      [lim] "=&v"(lim)
+#define CB_CHUNKED_INPUTS                                                                                        \
+  [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2), [miny2] "s"(miny2), [sx] "s"(sx),        \
+      [sy] "s"(sy), [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),            \
+      [tag] "v"(tag), [emit] "s"(emit), [tlx] "s"(tlx), [tly] "s"(tly), [chs] "s"(chs), [gcl] "s"(cursors_lds),  \
+      [one] "v"(1u)
+  const double rx = kPow2 ? 0.0 : ka->rcp_delta_real, ry = kPow2 ? 0.0 : ka->rcp_delta_imag;
+  const double kg = 0.5 - 0x1p-24;
+  const uint32_t all_steps = n_steps;
+  lane_steps = 0;
+  hits = 0;
+  for (;;) {  // the burst, resumed behind every step that had to open chunks
+  if (kPow2) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_HITS CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+                 : CB_CHUNKED_OUTPUTS
+                 : CB_CHUNKED_INPUTS, [ox] "v"(ox), [oy] "v"(oy)
+                 : "vcc", "scc", "memory");
+  } else {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_HITS CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+                 : CB_CHUNKED_OUTPUTS, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
+                 : CB_CHUNKED_INPUTS, [ox] "s"(ox), [oy] "s"(oy), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
+                 : "vcc", "scc", "memory");
+  }
+  lane_steps += cs;
+  hits += ch;
+  if (over == 0ull) {  // the burst ran to its end: ctr steps were left when the last lane stopped (0: none did)
+    if (burst_steps) *burst_steps = all_steps - (ctr != 0u ? ctr - 1u : 0u);
+    break;
+  }
+  // The lanes of `over` found their group's chunk full (or the group has none yet): their word is in e, the
+  // place they took in pos -- lim, lim + 1, ... in some order, one run per group.  Group by group: open the next
+  // free chunk, put the words at its start and the group's cursor behind them.  (Once per kChunkWords words of a
+  // group.)  The step itself is complete: ctr - 1 are left.
+  n_steps = __builtin_amdgcn_readfirstlane(ctr - 1u);
+  while (over != 0ull) {
+    const int lane0 = __ffsll((long long) over) - 1;
+    const uint32_t g0 = __builtin_amdgcn_readlane(grp, lane0);
+    const uint32_t lim0 = __builtin_amdgcn_readlane(lim, lane0);
+    const bool mine = lane_in(over) && grp == g0;
+    const unsigned long long same = __ballot(mine);
+    const uint32_t first = next_chunk * kChunkWords;
+    if (mine) region[first + (pos - lim0)] = e;
+    if (lane_id() == lane0) {
+      desc[next_chunk] = (g0 << 16) | kChunkWords;  // taken as full; the launch's end corrects the last one of each group
+      cursors[2u * g0] = first + (uint32_t) __popcll(same);
+      cursors[2u * g0 + 1u] = first + kChunkWords;
+    }
+    next_chunk++;
+    over &= ~same;
+  }
+  if (n_steps == 0u || act == 0ull) {
+    if (burst_steps) *burst_steps = all_steps - n_steps;
+    break;
+  }
+  }  // resumed
+#undef CB_CHUNKED_OUTPUTS
+#undef CB_CHUNKED_INPUTS
+}
+
 // ring index helpers for the 96-entry Q1 and the 192-entry Q2
 __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
 //
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
-template <bool kTimed, bool kBinned, bool kFastHead, bool kCount>
+template <bool kTimed, bool kBinned, bool kFastHead, bool kChunked>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // four waves per SIMD: at most 128 vector registers
 draw_wave_kernel(DrawArgs a) {
   static_assert(64 * kWavesPerBlock == kDrawBlockThreads, "draw_wave_count() assumes this block");
-  static_assert(!kCount || kBinned, "the level-A counts are counts of stream words");
+  static_assert(!kChunked || kBinned, "chunks are chunks of the stream");
   __shared__ WaveQueues queues[kWavesPerBlock];
   WaveQueues &q = queues[threadIdx.x >> 6];
-  // kCount: this wave's level-A counters of the two-level sort (CB_REPLAY_COUNT), 1 KiB per wave
-  __shared__ uint32_t group_counts[kCount ? kWavesPerBlock : 1][kCount ? kDrawCountKeys : 1];
-  uint32_t *const my_counts = group_counts[kCount ? (threadIdx.x >> 6) : 0];
-  if (kCount) {
-    for (uint32_t k = threadIdx.x & 63u; k < kDrawCountKeys; k += 64u) my_counts[k] = 0u;
+  // kChunked: {next word, end of chunk} of every group of 1024 tiles (kernels.h, kChunkWords), 512 B per wave
+  __shared__ uint32_t group_cursors[kChunked ? kWavesPerBlock : 1][kChunked ? 2 * kChunkedGroupsMax : 1];
+  uint32_t *const my_cursors = group_cursors[kChunked ? (threadIdx.x >> 6) : 0];
+  if (kChunked) {
+    for (uint32_t k = threadIdx.x & 63u; k < 2u * kChunkedGroupsMax; k += 64u) my_cursors[k] = 0u;  // no chunk yet
   }
-  const uint32_t group_counts_lds = kCount ? __builtin_amdgcn_readfirstlane(
-      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(my_counts))) : 0u;
+  const uint32_t cursors_lds = kChunked ? __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(my_cursors))) : 0u;
+  uint32_t next_chunk = 0;  // kChunked: chunks of this wave's segment in use
 
   // kBinned: this wave's region of the pixel stream (kernels.h, BinLayout)
   const uint32_t wave_id =
@@ -1440,17 +1504,31 @@ draw_wave_kernel(DrawArgs a) {
         // kBinned: the visited pixels go to this wave's stream region (compacted, coalesced stores)
         // in a hand-written burst; a full region falls back to the direct-atomics loop below, so
         // the result never depends on the workspace size.
-        if (kBinned && region_fill + 64u * kReplayBurst <= region_cap) {
+        // (kChunked: a burst opens at most one chunk per group and one per kChunkWords words)
+        const bool room = kChunked ? (next_chunk + a.bin.n_groups + 64u * kReplayBurst / kChunkWords + 1u <= a.bin.chunks_per_wave)
+                                   : (region_fill + 64u * kReplayBurst <= region_cap);
+        if (kBinned && room) {
           unsigned long long act_mask = __ballot(p_act);
           const unsigned long long was_act = act_mask;
           const unsigned long long emit = multi ? __ballot(p_real) : ~0ull;
           uint32_t steps = 0, hits = 0, burst = 0;
-          if (cv.pow2_real && cv.pow2_imag) {
-            replay_burst<true, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                       a.bin.e_row_shift, p_tag, emit, group_counts_lds, multi, kDbgReplay ? &burst : nullptr);
+          if (kChunked) {
+            uint32_t *const desc = a.bin.chunk_desc + (size_t) wave_id * a.bin.chunks_per_wave;
+            if (cv.pow2_real && cv.pow2_imag) {
+              replay_burst_chunked<true>(act_mask, kReplayBurst, po, p_steps, region, region_fill, steps, hits,
+                                         a.bin.e_row_shift, p_tag, emit, my_cursors, cursors_lds, next_chunk, desc,
+                                         kDbgReplay ? &burst : nullptr);
+            } else {
+              replay_burst_chunked<false>(act_mask, kReplayBurst, po, p_steps, region, region_fill, steps, hits,
+                                          a.bin.e_row_shift, p_tag, emit, my_cursors, cursors_lds, next_chunk, desc,
+                                          kDbgReplay ? &burst : nullptr);
+            }
+          } else if (cv.pow2_real && cv.pow2_imag) {
+            replay_burst<true>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                               a.bin.e_row_shift, p_tag, emit, multi, kDbgReplay ? &burst : nullptr);
           } else {
-            replay_burst<false, kCount>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
-                                        a.bin.e_row_shift, p_tag, emit, group_counts_lds, multi, kDbgReplay ? &burst : nullptr);
+            replay_burst<false>(act_mask, kReplayBurst, po, p_steps, cv, region, region_fill, steps, hits,
+                                a.bin.e_row_shift, p_tag, emit, multi, kDbgReplay ? &burst : nullptr);
           }
           if (kTimed && kDbgReplay) {  // the wave dump then describes REPLAY bursts instead of LONG chunks
             dbg_chunks += burst;
@@ -1797,16 +1875,16 @@ draw_wave_kernel(DrawArgs a) {
     default: break;
   }
   if (valid) store_rng(a.states, a.n_threads, tid, rng);
-  if (kBinned && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
-  if (kBinned && a.bin.draw_counted != nullptr) {
-    // who made the level-A counts of this launch's stream: this kernel (kCount) or nobody yet (group_count_kernel will)
-    if (wave_id == 0u && lane_id() == 0) *a.bin.draw_counted = kCount ? 1u : 0u;
-    if (kCount) {  // a_count[key][wave], as group_count_kernel lays it out
-      const uint32_t n_keys = a.bin.n_groups * kGroupReplicas;
-      for (uint32_t k = (uint32_t) lane_id(); k < n_keys; k += 64u) {
-        a.bin.a_count[(size_t) k * a.bin.n_waves + wave_id] = my_counts[k];
-      }
+  if (kBinned && !kChunked && lane_id() == 0) a.bin.wave_count[wave_id] = region_fill;
+  if (kChunked) {
+    // the last chunk of every group holds what its cursor says; every other chunk in use is full
+    uint32_t *const desc = a.bin.chunk_desc + (size_t) wave_id * a.bin.chunks_per_wave;
+    const uint32_t g = (uint32_t) lane_id();
+    if (g < a.bin.n_groups) {
+      const uint32_t pos = my_cursors[2u * g], lim = my_cursors[2u * g + 1u];
+      if (lim != 0u) desc[lim / kChunkWords - 1u] = (g << 16) | (pos - (lim - kChunkWords));
     }
+    if (lane_id() == 0) a.bin.wave_count[wave_id] = next_chunk;
   }
   if (carry) {  // leave queues and orbit slots for the next launch (empty after a drain)
     if (lane_id() == 0) {
@@ -1891,18 +1969,22 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   // survivors always have iterations left
   const bool fast = (a.head_steps == kHeadSteps) && (a.min_iter >= kHeadSteps) && (a.max_iter > kHeadSteps);
   const dim3 grid(blocks), block(threads);
-  // the level-A counts of the two-level sort made in the REPLAY burst (the product instances only)
-  const bool count = binned && !timed && a.bin.count_in_draw != 0u;
+  // beyond 1024 tiles: the stream chunked by group of tiles as it is written (BinLayout::chunked)
+  const bool chunked = binned && a.bin.chunked != 0u;
 #define CB_LAUNCH(T, B, F, C) hipLaunchKernelGGL((draw_wave_kernel<T, B, F, C>), grid, block, 0, stream, a)
   if (timed) {
     if (binned) {
-      if (fast) CB_LAUNCH(true, true, true, false); else CB_LAUNCH(true, true, false, false);
+      if (chunked) {
+        if (fast) CB_LAUNCH(true, true, true, true); else CB_LAUNCH(true, true, false, true);
+      } else {
+        if (fast) CB_LAUNCH(true, true, true, false); else CB_LAUNCH(true, true, false, false);
+      }
     } else {
       if (fast) CB_LAUNCH(true, false, true, false); else CB_LAUNCH(true, false, false, false);
     }
   } else {
     if (binned) {
-      if (count) {
+      if (chunked) {
         if (fast) CB_LAUNCH(false, true, true, true); else CB_LAUNCH(false, true, false, true);
       } else {
         if (fast) CB_LAUNCH(false, true, true, false); else CB_LAUNCH(false, true, false, false);

@@ -35,7 +35,16 @@ constexpr int kTilePixels = kTileSize * kTileSize;  // 16384 u32 counters = 64 K
 constexpr uint32_t kGroupTiles = 1024;              // keys of one region sort; more tiles: two levels
 constexpr uint32_t kMinRegionEntries = 4096;        // below this per wave the workspace is not used
 constexpr uint32_t kGroupReplicas = 4;              // level-A keys per group of the two-level sort (scatter.hip)
-constexpr uint32_t kDrawCountKeys = 256;            // level-A counters a draw wave keeps in LDS (count_in_draw)
+// Two levels, CHUNKED (up to kChunkedGroupsMax groups of 1024 tiles): level A happens where the words are born.
+// A wave's segment of the stream is cut into chunks of kChunkWords words; REPLAY appends a word to the current
+// chunk of its GROUP (cursor and limit of every group in the wave's LDS; a full chunk is followed by the next
+// free one of the segment) and notes the group of every chunk it opens in chunk_desc.  The scatter then sorts
+// REGIONS OF kRegionChunks CHUNKS of one group (lists of chunks instead of stretches of a grouped copy of the
+// stream): the stream is written once and read once, where the counting sort of level A read it twice more and
+// wrote it once more.
+constexpr uint32_t kChunkWords = 1024;
+constexpr uint32_t kRegionChunks = 32;              // 32 * 1024 = the 32768 entries of a region sort
+constexpr uint32_t kChunkedGroupsMax = 64;          // cursors: 64 x {next word, end of chunk} = 512 B of LDS per wave
 
 struct BinLayout {
   uint32_t enabled;     // 0: REPLAY adds to the histogram directly
@@ -49,9 +58,11 @@ struct BinLayout {
   // group's stretch of `grouped`, so that a region holds tiles of one group only; scatter.hip
   uint32_t two_level;
   uint32_t n_groups;    // 1 with one level
-  // two levels and n_groups * kGroupReplicas <= kDrawCountKeys: the draw kernel's REPLAY burst makes the level-A
-  // counts (a_count) itself and says so in *draw_counted; group_count_kernel then has nothing to do
-  uint32_t count_in_draw;
+  // two levels and n_groups <= kChunkedGroupsMax: the stream is chunked by group as it is written (above);
+  // wave_count then holds the chunks a wave has opened, a_count / a_base count and place CHUNKS, and `grouped`
+  // does not exist
+  uint32_t chunked;
+  uint32_t chunks_per_wave;  // cap / kChunkWords
   uint32_t max_regions;   // size of the region table and row length of run_start
   // Layout of a stream word: col in the low bits, row above it (e_row_shift), and -- fused multi-channel
   // renders only -- the index of the channel (plane) the point goes to above both (e_chan_shift,
@@ -73,7 +84,8 @@ struct BinLayout {
   uint32_t *group_first;          // [n_groups]           a group's regions are consecutive: the first ...
   uint32_t *group_regions;        // [n_groups]           ... and how many
   uint32_t *n_regions;            // [1] (+ the slice size and the entries of the launch behind it)
-  uint32_t *draw_counted;         // [1] 1: this launch's a_count comes from the draw kernel
+  uint32_t *chunk_desc;           // [n_waves][chunks_per_wave]  chunked: group << 16 | words in the chunk
+  uint2 *chunk_list;              // [n_waves * chunks_per_wave]  chunked: {first word, words} of every chunk, by group
   uint16_t *run_start;            // [min(n_tiles, 1024)][max_regions]  where tile k0 + i's run starts in a region
   uint32_t *slice_base;           // [n_tiles + 1]        exclusive prefix of accumulate workgroups per tile
   uint16_t *sorted;               // [n_waves * cap]      in-tile offsets, every region sorted by tile in place

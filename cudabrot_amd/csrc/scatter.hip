@@ -26,6 +26,12 @@
 // atomics).  Regions are then cut from each group's stretch of `grouped`, so every region holds tiles of
 // one group, and the two kernels above run unchanged with the group's first tile as key 0.
 //
+// Two levels, CHUNKED (up to 64 groups: 20000 x 20000, the three planes of the 20000 x 15000 recipe): level A is
+// done by the draw kernel as it writes -- a wave's segment is a set of chunks of 1024 words, each of one group
+// (kernels.h, kChunkWords).  What is left of level A here is bookkeeping on CHUNKS: count them per (group, wave),
+// scan, list them by group (chunk_count / group_scan_* / chunk_list), and cut regions of 32 chunks from each
+// group's stretch of the list.  The region sort reads its entries through the list; `grouped` does not exist.
+//
 // Increments commute, so the histogram is the same whatever the order; nothing here depends on timing
 // except the order of entries inside a run, which nothing reads.
 #include <stdlib.h>
@@ -111,7 +117,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
 __device__ __forceinline__ uint32_t owner_count(const BinLayout &b) { return b.two_level ? b.n_groups : b.n_waves; }
 __device__ __forceinline__ void owner_extent(const BinLayout &b, uint32_t o, unsigned long long *begin,
                                              unsigned long long *entries, uint32_t *piece) {
-  if (b.two_level) {
+  if (b.chunked) {  // in chunks: a group's stretch of chunk_list, regions of kRegionChunks chunks
+    *begin = b.a_base[o];
+    *entries = b.a_base[o + 1u] - *begin;
+    *piece = kRegionChunks;
+  } else if (b.two_level) {
     *begin = b.a_base[(size_t) o * kReplicas];
     *entries = b.a_base[(size_t) (o + 1u) * kReplicas] - *begin;
     *piece = kGroupRegionEntries;
@@ -146,7 +156,8 @@ __global__ void __launch_bounds__(1024) bin_region_heads_kernel(BinLayout b) {
   uint32_t r = block_exclusive_scan(mine, wave_totals, &total);
   // (block_exclusive_scan has a barrier behind the atomics above)
   if (threadIdx.x == 0) {  // entries of the launch, for the slice size (n_regions[2..3] as one 64-bit word)
-    *reinterpret_cast<unsigned long long *>(b.n_regions + 2) = all_entries;
+    // (chunked: chunks were counted -- taken as full, the figure only steers the slice size)
+    *reinterpret_cast<unsigned long long *>(b.n_regions + 2) = b.chunked ? all_entries * kChunkWords : all_entries;
   }
   for (uint32_t k = 0; k < per; ++k) {
     const uint32_t o = o0 + k;
@@ -259,8 +270,8 @@ template <bool kFewTiles>
 struct SortLds {
   static constexpr uint32_t kReplicas = kFewTiles ? 8u : 2u;
   static constexpr uint32_t kStride = (kFewTiles ? 256u : kGroupTiles) + 16u;  // counters of a replica + the dummy
-  static constexpr size_t kBytes =
-      (kReplicas * kStride + 16) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
+  static constexpr size_t kBytes =  // counters | wave_totals[16] | chunks of the region[32] {first word, words} | image
+      (kReplicas * kStride + 16 + 2 * kRegionChunks + 4) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
 };
 constexpr uint32_t kFewTilesMax = 256;
 #ifndef CB_SORT_GRID
@@ -279,14 +290,18 @@ __device__ __forceinline__ uint32_t sort_word(uint32_t e, uint32_t k0, const Bin
   return ((tile_of(e, b) - k0) << 16) | offset_of(e, b);
 }
 
-template <bool kPlain, bool kFewTiles>
+// kChunked (BinLayout::chunked): the region is a list of at most kRegionChunks chunks of the stream (region_start:
+// first entry of chunk_list, region_count: chunks) instead of a stretch of it; its image goes to sorted[r * 32768]
+// and region_count[r] becomes its number of entries, which is what the gather reads.
+template <bool kPlain, bool kFewTiles, bool kChunked = false>
 __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b) {
   constexpr uint32_t kCntReplicas = SortLds<kFewTiles>::kReplicas, kCntStride = SortLds<kFewTiles>::kStride;
   constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
   extern __shared__ uint32_t lds[];
   uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
-  uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16);
+  uint2 *chunks = reinterpret_cast<uint2 *>(lds + kCntReplicas * kCntStride + 16);
+  uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16 + 2 * kRegionChunks + 4);  // (+ the words of the region)
 
   // The grid is kSortGrid workgroups striding over the regions: how many regions a launch has is only known on
   // the device, and a grid sized for the most it could have spends 11 ns on every workgroup that finds nothing
@@ -294,21 +309,66 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   // resident workgroups was 12 % slower: the two workgroups of a CU fall into step.)
   const uint32_t n_regions = *b.n_regions;
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-  const uint32_t n = b.region_count[r];
-  const unsigned long long start = b.region_start[r];
-  const uint32_t *src = (b.two_level ? b.grouped : b.stream) + start;
+  uint32_t n = kChunked ? 0u : b.region_count[r];
+  const unsigned long long start = kChunked ? (unsigned long long) r * kRegionEntries : b.region_start[r];
+  const uint32_t *src = kChunked ? b.stream : (b.two_level ? b.grouped : b.stream) + start;
   const uint32_t k0 = b.region_group[r] << kGroupShift;
   const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
   __syncthreads();  // (a further region of this workgroup: the previous image has left)
   for (uint32_t t = threadIdx.x; t < kCntReplicas * kCntStride; t += kSortThreads) lds[t] = 0u;
+  if (kChunked && threadIdx.x < 64u) {  // the first wave: the region's chunks, and the sum of their words
+    const uint32_t n_chunks = b.region_count[r];
+    // a chunk the region does not have: no words (its loads read the start of the stream and are ignored)
+    const uint2 c = threadIdx.x < n_chunks && threadIdx.x < kRegionChunks ? b.chunk_list[b.region_start[r] + threadIdx.x]
+                                                                          : make_uint2(0u, 0u);
+    if (threadIdx.x < kRegionChunks) chunks[threadIdx.x] = c;
+    uint32_t words = c.y;
+#pragma unroll
+    for (uint32_t d = 32; d >= 1; d >>= 1) words += __shfl_xor(words, d, 64);
+    if (threadIdx.x == 0) chunks[kRegionChunks].x = words;
+  }
   __syncthreads();
+  if (kChunked) n = chunks[kRegionChunks].x;
 
   // 1. the region's entries, once: e[k] = (key << 16) | in-tile offset, ~0 beyond the region; counts per tile.
   // Which thread takes which entry does not matter: 16-byte loads from the 16-byte boundary below the region
   // (a region of a group starts anywhere; `head` entries before it are masked, and regions that may start
   // off a boundary are cut 8 entries short so that head + n still fits the 32 per thread).
   uint32_t e[kSortPerThread];
-  {
+  if constexpr (kChunked) {
+    // 16-byte load i4 of the region = load i4 % 256 of its chunk i4 / 256 (a chunk: 1024 words on a 4 KiB boundary)
+    static_assert(kChunkWords == 1024 && kSortThreads == 1024, "a load instruction of the workgroup covers four chunks");
+    const uint4 *stream4 = reinterpret_cast<const uint4 *>(b.stream);
+    // batches of two loads (the addresses are 64-bit here -- a chunk may lie anywhere in 16 GiB -- and four in
+    // flight with their addresses cost the second workgroup of a CU)
+#pragma unroll
+    for (uint32_t pair = 0; pair < kSortPerThread / 8u; ++pair) {
+      uint4 v[2];
+#pragma unroll
+      for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t i4 = (pair * 2u + j) * kSortThreads + threadIdx.x;
+        v[j] = stream4[(size_t) (chunks[i4 >> 8].x >> 2) + (i4 & 255u)];
+      }
+#pragma unroll
+      for (uint32_t j = 0; j < 2; ++j) {
+        asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
+        const uint32_t k = pair * 2u + j;
+        const uint32_t words = chunks[(k * kSortThreads + threadIdx.x) >> 8].y;
+        const uint32_t i = (threadIdx.x & 255u) * 4u;  // index of the load's first word inside its chunk
+        const uint32_t w0 = sort_word<kPlain>(v[j].x, k0, b), w1 = sort_word<kPlain>(v[j].y, k0, b);
+        const uint32_t w2 = sort_word<kPlain>(v[j].z, k0, b), w3 = sort_word<kPlain>(v[j].w, k0, b);
+        e[4 * k + 0] = (i < words) ? w0 : ~0u;
+        e[4 * k + 1] = (i + 1u < words) ? w1 : ~0u;
+        e[4 * k + 2] = (i + 2u < words) ? w2 : ~0u;
+        e[4 * k + 3] = (i + 3u < words) ? w3 : ~0u;
+      }
+#pragma unroll
+      for (uint32_t k = pair * 8u; k < (pair + 1u) * 8u; ++k) {
+        const uint32_t key = e[k] >> 16;  // 0xffff beyond the chunk's words
+        lds_inc(&cnt[key < kDummyKey ? key : kDummyKey]);
+      }
+    }
+  } else {
     const uint32_t head = (uint32_t) (start & 3ull);
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src - head);
     const uint32_t lim = head + n;
@@ -390,6 +450,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   } else {
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
   }
+  if (kChunked && threadIdx.x == 0) b.region_count[r] = n;  // from chunks to entries (every region is sorted once)
   }  // regions of this workgroup
 }
 
@@ -440,7 +501,8 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
     Run run = {reinterpret_cast<const uint4 *>(b.sorted), 0u, 0u};  // lanes without a run load (and ignore) the first bytes
     const uint32_t rr = base + lane;
     if (rr < r1) {
-      const unsigned long long rs = b.region_start[first + rr];
+      // (chunked: region r's image is sorted[r * 32768 ...]; region_start there names its chunks)
+      const unsigned long long rs = b.chunked ? (unsigned long long) (first + rr) * kRegionEntries : b.region_start[first + rr];
       const unsigned long long beg = rs + row0[rr];
       const unsigned long long end = rs + (last_key ? b.region_count[first + rr] : (uint32_t) row1[rr]);
       if (end != beg) {  // an empty run reads nothing
@@ -512,7 +574,6 @@ __device__ __forceinline__ uint32_t group_key(const BinLayout &b, uint32_t e, ui
 
 __global__ void __launch_bounds__(kScatterThreads) group_count_kernel(BinLayout b) {
   extern __shared__ uint32_t lds[];  // [n_groups * kReplicas]
-  if (*b.draw_counted != 0u) return;  // the draw kernel counted its words as it wrote them (CB_REPLAY_COUNT)
   const uint32_t r = blockIdx.x;
   const uint32_t n = wave_count_of(b, r);
   const uint32_t *src = b.stream + (size_t) r * b.cap;  // 16-byte aligned: cap is a multiple of 8
@@ -533,6 +594,45 @@ __global__ void __launch_bounds__(kScatterThreads) group_count_kernel(BinLayout 
   __syncthreads();
   // key-major: the scan over waves reads each key's row contiguously
   for (uint32_t t = threadIdx.x; t < nk; t += blockDim.x) b.a_count[(size_t) t * b.n_waves + r] = lds[t];
+}
+
+// ---- chunked level A: the chunks of the stream, listed by group ---------------------------------------
+//
+// chunk_desc[w][j] = group << 16 | words for the chunks j < wave_count[w] of wave w (written by the draw kernel).
+// chunk_count: a_count[g][w] = chunks of group g in wave w; group_scan_rows / group_scan_keys make the exclusive
+// prefixes (over waves per group, over groups); chunk_list: chunk_list[a_base[g] + a_count[g][w] + rank] =
+// {first word of the chunk in the stream, words} -- the order of a (group, wave)'s chunks among themselves is
+// whatever the atomics give, which nothing depends on.
+__global__ void __launch_bounds__(64) chunk_count_kernel(BinLayout b) {
+  __shared__ uint32_t cnt[kChunkedGroupsMax];
+  const uint32_t w = blockIdx.x;
+  cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t n = b.wave_count[w] < b.chunks_per_wave ? b.wave_count[w] : b.chunks_per_wave;
+  const uint32_t *desc = b.chunk_desc + (size_t) w * b.chunks_per_wave;
+  for (uint32_t j = threadIdx.x; j < n; j += 64u) {
+    const uint32_t g = desc[j] >> 16;
+    if (g < b.n_groups) lds_inc(&cnt[g]);
+  }
+  __syncthreads();
+  if (threadIdx.x < b.n_groups) b.a_count[(size_t) threadIdx.x * b.n_waves + w] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(64) chunk_list_kernel(BinLayout b) {
+  __shared__ uint32_t cnt[kChunkedGroupsMax];
+  const uint32_t w = blockIdx.x;
+  cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t n = b.wave_count[w] < b.chunks_per_wave ? b.wave_count[w] : b.chunks_per_wave;
+  const uint32_t *desc = b.chunk_desc + (size_t) w * b.chunks_per_wave;
+  for (uint32_t j = threadIdx.x; j < n; j += 64u) {
+    const uint32_t d = desc[j], g = d >> 16;
+    if (g >= b.n_groups) continue;  // (never written by the draw kernel)
+    const uint32_t words = (d & 0xffffu) < kChunkWords ? (d & 0xffffu) : kChunkWords;
+    const uint32_t rank = __hip_atomic_fetch_add(&cnt[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long at = b.a_base[g] + b.a_count[(size_t) g * b.n_waves + w] + rank;
+    b.chunk_list[at] = make_uint2(w * b.cap + j * kChunkWords, words);  // all entries together are < 2^32
+  }
 }
 
 // a_count[key][w] <- sum of a_count[key][w'] for w' < w; a_base[key] <- total of the key (scanned next).
@@ -561,7 +661,7 @@ __global__ void __launch_bounds__(256) group_scan_rows_kernel(BinLayout b) {
 // a_base[key] <- sum of totals of keys < key (a_base[n] <- grand total).  One workgroup.
 __global__ void __launch_bounds__(1024) group_scan_keys_kernel(BinLayout b) {
   __shared__ unsigned long long part[1024];
-  const uint32_t nk = b.n_groups * kReplicas;  // <= 1024
+  const uint32_t nk = b.chunked ? b.n_groups : b.n_groups * kReplicas;  // <= 1024
   const unsigned long long v = threadIdx.x < nk ? b.a_base[threadIdx.x] : 0ull;
   part[threadIdx.x] = v;
   __syncthreads();
@@ -661,10 +761,11 @@ __global__ void __launch_bounds__(kScatterThreads) group_scatter_kernel(BinLayou
 struct Shape {
   bool ok;
   uint32_t tiles_x, n_tiles, two_level, n_groups, tiles_y;  // n_tiles: of all planes together
+  uint32_t chunked;  // two levels, level A by the draw kernel (kernels.h, kChunkWords)
 };
 
 Shape shape_of(int w, int h, uint32_t planes) {
-  Shape s = {false, 0, 0, 0, 0, 0};
+  Shape s = {false, 0, 0, 0, 0, 0, 0};
   if (w <= 0 || h <= 0 || w > 65536 || h > 65536 || planes < 1u) return s;
   const uint32_t tiles_x = ((uint32_t) w + kTileSize - 1u) >> kTileShift;
   const uint32_t tiles_y = ((uint32_t) h + kTileSize - 1u) >> kTileShift;
@@ -679,12 +780,17 @@ Shape shape_of(int w, int h, uint32_t planes) {
     if (atoi(e) != 0) s.two_level = 1u;
   }
   s.n_groups = (s.n_tiles + kGroupTiles - 1u) / kGroupTiles;
+  s.chunked = (s.two_level && s.n_groups <= kChunkedGroupsMax) ? 1u : 0u;
+  if (const char *e = getenv("CUDABROT_AMD_CHUNKED")) {  // test knob: 0 = level A as a counting sort over the stream
+    if (atoi(e) == 0) s.chunked = 0u;
+  }
   return s;
 }
 
 // Upper bound on the number of regions for `entries` stream entries: every wave segment (one level) or
 // group (two levels) ends with one partial region.
 uint32_t max_regions_for(const Shape &s, uint32_t n_waves, unsigned long long entries) {
+  if (s.chunked) return (uint32_t) (entries / kRegionEntries) + s.n_groups + 1u;  // entries = chunks * kChunkWords
   if (s.two_level) return (uint32_t) (entries / kGroupRegionEntries) + s.n_groups + 1u;
   return (uint32_t) (entries / kRegionEntries) + n_waves + 1u;
 }
@@ -702,14 +808,18 @@ size_t fixed_bytes(const Shape &s, uint32_t n_waves, uint32_t max_regions) {
   b += round_up(rows * max_regions * sizeof(uint16_t), 256);                        // run_start
   b += round_up(((size_t) s.n_tiles + 1) * sizeof(uint32_t), 256);                  // slice_base
   if (s.two_level) {
-    const size_t keys = (size_t) s.n_groups * kReplicas;
+    const size_t keys = (size_t) s.n_groups * kReplicas;  // (chunked: n_groups rows are used)
     b += round_up(keys * n_waves * sizeof(uint32_t), 256);                          // a_count
     b += round_up((keys + 1) * sizeof(unsigned long long), 256);                    // a_base
   }
+  if (s.chunked) b += round_up((size_t) max_regions * kRegionEntries * sizeof(uint16_t), 256);  // sorted: an image per region
   return b + 1024;
 }
 
+// per entry of the stream (chunked: the stream, and per chunk of 1024 a descriptor and a list entry, counted as
+// 1 byte per entry; `sorted` is sized by the regions, fixed_bytes)
 size_t bytes_per_entry(const Shape &s) {
+  if (s.chunked) return sizeof(uint32_t) + 1;
   return sizeof(uint32_t) + sizeof(uint16_t) + (s.two_level ? sizeof(uint32_t) : 0);
 }
 
@@ -734,6 +844,7 @@ size_t bin_workspace_bytes(int w, int h, uint32_t n_waves, double entries_per_wa
   const Shape s = shape_of(w, h, (uint32_t) (n_planes > 0 ? n_planes : 1));
   if (!s.ok || n_waves == 0) return 0;
   if (entries_per_wave < 2.0 * kMinRegionEntries) entries_per_wave = 2.0 * kMinRegionEntries;
+  if (s.chunked) entries_per_wave += (double) (s.n_groups + 3u) * kChunkWords;  // a partly filled chunk per group, and the room a burst asks for
   const unsigned long long entries = (unsigned long long) (entries_per_wave * n_waves);
   return fixed_bytes(s, n_waves, max_regions_for(s, n_waves, entries)) + entries * bytes_per_entry(s) + 8192;
 }
@@ -783,12 +894,13 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   if (cap > cap_limit) cap = cap_limit;
   for (;;) {
     cap &= ~7ull;  // segments start on 16-byte boundaries of the 16-bit sorted image too
+    if (s.chunked) cap &= ~(unsigned long long) (kChunkWords - 1u);  // a segment is a whole number of chunks
     if (cap < kMinRegionEntries) return b;
     const uint32_t mr = max_regions_for(s, n_waves, cap * n_waves);
     const size_t need = fixed_bytes(s, n_waves, mr) + (size_t) cap * n_waves * per_entry + 1024;
     if (p + need <= p_end) break;
     const size_t over = p + need - p_end;
-    const unsigned long long cut = over / (per_entry * (size_t) n_waves) + 8;
+    const unsigned long long cut = over / (per_entry * (size_t) n_waves) + (s.chunked ? kChunkWords : 8u);
     if (cut >= cap) return b;
     cap -= cut;
   }
@@ -803,8 +915,8 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   b.group_regions = carve<uint32_t>(p, (size_t) kMaxGroups * sizeof(uint32_t));
   b.owner_first = carve<uint32_t>(p, ((size_t) (n_waves > kMaxGroups ? n_waves : kMaxGroups) + 1) * sizeof(uint32_t));
   b.n_regions = carve<uint32_t>(p, 256);
-  b.draw_counted = b.n_regions + 8;
-  b.count_in_draw = (b.two_level && b.n_groups * kReplicas <= kDrawCountKeys) ? 1u : 0u;
+  b.chunked = s.chunked;
+  b.chunks_per_wave = s.chunked ? b.cap / kChunkWords : 0u;
   b.run_start = carve<uint16_t>(p, rows * b.max_regions * sizeof(uint16_t));
   b.slice_base = carve<uint32_t>(p, ((size_t) b.n_tiles + 1) * sizeof(uint32_t));
   if (b.two_level) {
@@ -813,8 +925,14 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
     b.a_base = carve<unsigned long long>(p, (keys + 1) * sizeof(unsigned long long));
   }
   b.stream = carve<uint32_t>(p, (size_t) n_waves * b.cap * sizeof(uint32_t));
-  if (b.two_level) b.grouped = carve<uint32_t>(p, (size_t) n_waves * b.cap * sizeof(uint32_t));
-  b.sorted = carve<uint16_t>(p, (size_t) n_waves * b.cap * sizeof(uint16_t));
+  if (b.chunked) {
+    b.chunk_desc = carve<uint32_t>(p, (size_t) n_waves * b.chunks_per_wave * sizeof(uint32_t));
+    b.chunk_list = carve<uint2>(p, (size_t) n_waves * b.chunks_per_wave * sizeof(uint2));
+    b.sorted = carve<uint16_t>(p, (size_t) b.max_regions * kRegionEntries * sizeof(uint16_t));
+  } else {
+    if (b.two_level) b.grouped = carve<uint32_t>(p, (size_t) n_waves * b.cap * sizeof(uint32_t));
+    b.sorted = carve<uint16_t>(p, (size_t) n_waves * b.cap * sizeof(uint16_t));
+  }
   b.enabled = 1;
   return b;
 }
@@ -822,7 +940,12 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream) {
   if (!b.enabled) return hipSuccess;
-  if (b.two_level) {
+  if (b.chunked) {
+    hipLaunchKernelGGL(chunk_count_kernel, dim3(b.n_waves), dim3(64), 0, stream, b);
+    hipLaunchKernelGGL(group_scan_rows_kernel, dim3(b.n_groups), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(group_scan_keys_kernel, dim3(1), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(chunk_list_kernel, dim3(b.n_waves), dim3(64), 0, stream, b);
+  } else if (b.two_level) {
     const uint32_t nk = b.n_groups * kReplicas;
     hipLaunchKernelGGL(group_count_kernel, dim3(b.n_waves), dim3(kScatterThreads), nk * sizeof(uint32_t), stream, b);
     hipLaunchKernelGGL(group_scan_rows_kernel, dim3(nk), dim3(256), 0, stream, b);
@@ -851,7 +974,10 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     return hipSuccess;
   };
   hipError_t se;
-  if (few) {
+  if (b.chunked) {
+    se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
+               : launch_sort(bin_region_sort_kernel<false, false, true>, SortLds<false>::kBytes);
+  } else if (few) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, true>, SortLds<true>::kBytes);
   } else {

@@ -65,8 +65,10 @@ def test_each_plane_equals_a_separate_run(cb, oracle, windows, mode):
     assert int(planes.sum()) == total
 
 
-def test_fused_channels_on_a_canvas_that_divides_and_needs_two_sort_levels(cb, oracle, monkeypatch):
+@pytest.mark.parametrize("chunked", ["1", "0"])
+def test_fused_channels_on_a_canvas_that_divides_and_needs_two_sort_levels(cb, oracle, monkeypatch, chunked):
     monkeypatch.setenv("CUDABROT_AMD_TWO_LEVEL", "1")
+    monkeypatch.setenv("CUDABROT_AMD_CHUNKED", chunked)  # level A: chunked by the draw kernel / a counting sort
     box = (-2.0, 1.5, -1.4, 1.4)
     windows = [(200, 20), (1500, 200)]
     w, h, t, passes = 700, 450, 8192, 3

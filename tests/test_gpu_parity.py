@@ -280,11 +280,15 @@ def test_canvas_that_cannot_use_the_workspace(cb, oracle):
     assert_same(got, cpu)
 
 
+@pytest.mark.parametrize("chunked", ["1", "0"])
 @pytest.mark.parametrize("shape", [(700, 500), (1300, 900)])
-def test_two_level_sort_on_a_small_canvas(cb, oracle, monkeypatch, shape):
+def test_two_level_sort_on_a_small_canvas(cb, oracle, monkeypatch, shape, chunked):
     """The two-level sort of scatter.hip (groups of 1024 tiles, then tiles) forced on canvases that one
-    level would handle: same histogram.  1300 x 900 has 88 tiles; 700 x 500 has 24 (one partial group)."""
+    level would handle: same histogram.  1300 x 900 has 88 tiles; 700 x 500 has 24 (one partial group).
+    Level A in both its forms: the stream chunked by group as the draw kernel writes it (what canvases of up to
+    64 groups get), and the counting sort over the stream (CUDABROT_AMD_CHUNKED=0: what larger ones get)."""
     monkeypatch.setenv("CUDABROT_AMD_TWO_LEVEL", "1")
+    monkeypatch.setenv("CUDABROT_AMD_CHUNKED", chunked)
     w, h = shape
     t, passes = 8192, 3
     dims = cb.FractalDimensions.make(w, h)
@@ -295,14 +299,29 @@ def test_two_level_sort_on_a_small_canvas(cb, oracle, monkeypatch, shape):
     assert_same(got, cpu)
 
 
-def test_canvas_beyond_4096_tiles_uses_two_levels(cb, oracle):
+@pytest.mark.parametrize("chunked", ["1", "0"])
+def test_canvas_beyond_4096_tiles_uses_two_levels(cb, oracle, monkeypatch, chunked):
     """9100 x 8300 pixels = 72 x 65 = 4680 tiles of 128 x 128: five groups, the last one partial; a box
     that is not a power-of-two grid, so the binning divides (cudabrot.cu:308-311)."""
+    monkeypatch.setenv("CUDABROT_AMD_CHUNKED", chunked)
     w, h, t, passes = 9100, 8300, 16384, 2
     box = (-2.0, 1.5, -1.6, 1.6)
     dims = cb.FractalDimensions.make(w, h, *box)
     size = cb.scatter_workspace_bytes(dims, t, 50)
     assert size > 0
+    got = _torch_render(cb, w, h, 400, 20, t, passes, size, box=box)
+    cpu = oracle.render(w, h, 400, 20, t, passes, box, omp_threads=0)
+    assert_same(got, cpu)
+
+
+@pytest.mark.parametrize("fraction", [0.3, 0.6, 0.8])
+def test_chunked_stream_that_runs_out_of_chunks(cb, oracle, fraction):
+    """Five groups, and a workspace smaller than the launch needs: a wave that has not enough free chunks left for
+    a burst adds its increments to the histogram directly -- the result does not depend on the workspace."""
+    w, h, t, passes = 9100, 8300, 16384, 2
+    box = (-2.0, 1.5, -1.6, 1.6)
+    dims = cb.FractalDimensions.make(w, h, *box)
+    size = int(cb.scatter_workspace_bytes(dims, t, 50) * fraction)
     got = _torch_render(cb, w, h, 400, 20, t, passes, size, box=box)
     cpu = oracle.render(w, h, 400, 20, t, passes, box, omp_threads=0)
     assert_same(got, cpu)
