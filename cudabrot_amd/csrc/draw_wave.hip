@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 // LDS at gcl + 8 * group: one returning add takes the place, lanes that find it behind the end of the chunk
 // (`over`) keep their word in e -- the burst then ends with this step and the caller opens new chunks for them
 // (replay_burst_chunked).  row and col are free once the word is formed.
-#define CB_REPLAY_CHUNKED                                 \
+#define CB_REPLAY_GROUP_TAGGED  /* fused channels: the planes are one canvas of n_planes * tiles_y tile rows */ \
   "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
   "s_mov_b64 exec, vcc\n\t"                               \
   "v_lshrrev_b32 %[pl], %[chs], %[tag]\n\t"               \
@@ -1021,7 +1021,15 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_lshrrev_b32 %[col], 7, %[col]\n\t"                   \
   "v_mad_u32_u24 %[row], %[pl], %[tly], %[row]\n\t"       \
   "v_mad_u32_u24 %[row], %[row], %[tlx], %[col]\n\t"      \
-  "v_lshrrev_b32 %[grp], 10, %[row]\n\t"                  \
+  "v_lshrrev_b32 %[grp], 10, %[row]\n\t"
+#define CB_REPLAY_GROUP_PLAIN                             \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "v_lshrrev_b32 %[row], 7, %[row]\n\t"                   \
+  "v_lshrrev_b32 %[col], 7, %[col]\n\t"                   \
+  "v_mad_u32_u24 %[row], %[row], %[tlx], %[col]\n\t"      \
+  "v_lshrrev_b32 %[grp], 10, %[row]\n\t"
+#define CB_REPLAY_CHUNKED                                 \
   "v_lshl_add_u32 %[col], %[grp], 3, %[gcl]\n\t"          \
   "ds_add_rtn_u32 %[pos], %[col], %[one]\n\t"             \
   "ds_read_b32 %[lim], %[col] offset:4\n\t"               \
@@ -1044,6 +1052,16 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "s_and_b64 vcc, vcc, %[emit]\n\t"
+#define CB_REPLAY_TAIL_HITS_PLAIN                         \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
+  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
+  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"
 #define CB_REPLAY_TAIL2_CHUNKED                           \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
@@ -1187,9 +1205,9 @@ template <bool kPow2>
 __device__ __forceinline__ void replay_burst_chunked(unsigned long long &act, uint32_t n_steps, Orbit &p,
                                                      int &p_steps, uint32_t *region, uint32_t &fill,
                                                      uint32_t &lane_steps, uint32_t &hits, uint32_t row_shift,
-                                                     uint32_t tag, unsigned long long emit, uint32_t *cursors,
-                                                     uint32_t cursors_lds, uint32_t &next_chunk, uint32_t *desc,
-                                                     uint32_t *burst_steps = nullptr) {
+                                                     uint32_t tag, unsigned long long emit, bool tagged,
+                                                     uint32_t *cursors, uint32_t cursors_lds, uint32_t &next_chunk,
+                                                     uint32_t *desc, uint32_t *burst_steps = nullptr) {
   unsigned long long save, alive, hx, hy, scp, over;
   uint32_t cs, ch, ctr, t;
   double a, fx, fy, d0, d1, d2, d3;
@@ -1225,13 +1243,25 @@ __device__ __forceinline__ void replay_burst_chunked(unsigned long long &act, ui
   lane_steps = 0;
   hits = 0;
   for (;;) {  // the burst, resumed behind every step that had to open chunks
-  if (kPow2) {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_HITS CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+  act = uniform_u64(act);  // (wave-uniform by construction; provably so for the "s" operands below)
+  fill = __builtin_amdgcn_readfirstlane(fill);
+  if (kPow2 && tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_HITS CB_REPLAY_GROUP_TAGGED CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
                  : CB_CHUNKED_OUTPUTS
                  : CB_CHUNKED_INPUTS, [ox] "v"(ox), [oy] "v"(oy)
                  : "vcc", "scc", "memory");
+  } else if (kPow2) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_POW2 CB_REPLAY_TAIL_HITS_PLAIN CB_REPLAY_GROUP_PLAIN CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+                 : CB_CHUNKED_OUTPUTS
+                 : CB_CHUNKED_INPUTS, [ox] "v"(ox), [oy] "v"(oy)
+                 : "vcc", "scc", "memory");
+  } else if (tagged) {
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_HITS CB_REPLAY_GROUP_TAGGED CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+                 : CB_CHUNKED_OUTPUTS, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
+                 : CB_CHUNKED_INPUTS, [ox] "s"(ox), [oy] "s"(oy), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
+                 : "vcc", "scc", "memory");
   } else {
-    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_HITS CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
+    asm volatile(CB_REPLAY_HEAD CB_REPLAY_BIN_DIV CB_REPLAY_TAIL_HITS_PLAIN CB_REPLAY_GROUP_PLAIN CB_REPLAY_CHUNKED CB_REPLAY_TAIL2_CHUNKED
                  : CB_CHUNKED_OUTPUTS, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
                  : CB_CHUNKED_INPUTS, [ox] "s"(ox), [oy] "s"(oy), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
                  : "vcc", "scc", "memory");
@@ -1516,11 +1546,11 @@ draw_wave_kernel(DrawArgs a) {
             uint32_t *const desc = a.bin.chunk_desc + (size_t) wave_id * a.bin.chunks_per_wave;
             if (cv.pow2_real && cv.pow2_imag) {
               replay_burst_chunked<true>(act_mask, kReplayBurst, po, p_steps, region, region_fill, steps, hits,
-                                         a.bin.e_row_shift, p_tag, emit, my_cursors, cursors_lds, next_chunk, desc,
+                                         a.bin.e_row_shift, p_tag, emit, multi, my_cursors, cursors_lds, next_chunk, desc,
                                          kDbgReplay ? &burst : nullptr);
             } else {
               replay_burst_chunked<false>(act_mask, kReplayBurst, po, p_steps, region, region_fill, steps, hits,
-                                          a.bin.e_row_shift, p_tag, emit, my_cursors, cursors_lds, next_chunk, desc,
+                                          a.bin.e_row_shift, p_tag, emit, multi, my_cursors, cursors_lds, next_chunk, desc,
                                           kDbgReplay ? &burst : nullptr);
             }
           } else if (cv.pow2_real && cv.pow2_imag) {
