@@ -913,7 +913,10 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 //                       describe (sides <= 65536), whatever the conversion yields.  If any lane of the
 //                       step fails the test (|fract(q') - 1/2| < 1/2 - 2^-24; a NaN or infinite estimate
 //                       fails it too) the whole wave takes the exact division: about one step in 10^7.
-// The tests re >= min_re, im >= min_im are made on the doubled values (R >= 2 min_re).  The hits of a
+// The four tests re >= min_re, col < w (and im, row) are two: the quotient q = (re - min_re) / d_re has the sign of
+// re - min_re (-0.0 included: a negative difference never rounds to +0), and for q >= 0 trunc(q) < w iff q < w, so
+// 0 <= q < w -- as ONE unsigned 64-bit compare of q's bits with those of (double) w: a set sign bit or a NaN is
+// above any such bound, and so is every q that the reference's (int) conversion would saturate.  The hits of a
 // step are compacted with v_mbcnt and stored side by side (one coalesced store).  The stream word is
 // row << rsh | col | tag (one channel: rsh = 16, tag = 0; fused channels: the index of the pass's channel above
 // row and col), and only the lanes of `emit` write (fused channels: not the lanes still measuring
@@ -967,9 +970,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"                 \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_add_u32 %[ps], 1, %[ps]\n\t"                         \
-  "v_cmp_le_f64_e64 %[hy], %[miny2], %[i]\n\t"            \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
-  "v_cmp_le_f64_e64 %[hx], %[minx2], %[r]\n\t"            \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
 // ..._TAGGED: fused channels (the word carries the channel's tag, lanes still measuring do not write);
 // ..._PLAIN: one channel -- no tag, every lane of the step writes.
@@ -977,11 +978,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
-  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
-  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
   "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "s_and_b64 vcc, vcc, %[emit]\n\t"                       \
@@ -995,11 +994,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
-  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
-  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
   "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
   "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
@@ -1044,11 +1041,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
-  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
-  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
   "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "v_or_b32 %[e], %[e], %[tag]\n\t"                       \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "s_and_b64 vcc, vcc, %[emit]\n\t"
@@ -1056,11 +1051,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
-  "v_cmp_gt_u32_e64 %[hy], %[w], %[col]\n\t"              \
-  "v_cmp_gt_u32_e64 vcc, %[h], %[row]\n\t"                \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
   "v_lshl_or_b32 %[e], %[row], %[rsh], %[col]\n\t"        \
-  "s_and_b64 %[hx], %[hx], %[hy]\n\t"                     \
   "s_and_b64 vcc, vcc, %[hx]\n\t"
 #define CB_REPLAY_TAIL2_CHUNKED                           \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
@@ -1115,8 +1108,7 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
   // All "s" operands are wave-uniform by construction; uniform_*/readfirstlane make that provable.
   (void) cv;
   const KernelArgs ka = fresh_args();
-  const double minx2 = ka->replay_min2_real, miny2 = ka->replay_min2_imag;
-  const uint32_t w = (uint32_t) ka->w, h = (uint32_t) ka->h;
+  const double wb = (double) ka->w, hb = (double) ka->h;  // the bounds of the quotients, compared as bit patterns
   region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
@@ -1136,9 +1128,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
                    [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
     } else {
@@ -1148,9 +1139,8 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a),
                    [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox), [oy] "v"(oy),
+                   [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
     }
@@ -1167,10 +1157,9 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
                    [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
                    [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
     } else {
@@ -1181,10 +1170,9 @@ __device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n
                    [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [d0] "=&v"(d0),
                    [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col), [row] "=&v"(row),
                    [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2),
-                   [miny2] "s"(miny2), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox), [oy] "s"(oy),
                    [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg),
-                   [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
+                   [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),
                    [tag] "v"(tag), [emit] "s"(emit)
                  : "vcc", "scc", "memory");
     }
@@ -1213,8 +1201,7 @@ __device__ __forceinline__ void replay_burst_chunked(unsigned long long &act, ui
   double a, fx, fy, d0, d1, d2, d3;
   uint32_t col, row, pidx, e, pl, grp, pos, lim;
   const KernelArgs ka = fresh_args();
-  const double minx2 = ka->replay_min2_real, miny2 = ka->replay_min2_imag;
-  const uint32_t w = (uint32_t) ka->w, h = (uint32_t) ka->h;
+  const double wb = (double) ka->w, hb = (double) ka->h;  // the bounds of the quotients, compared as bit patterns
   region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
@@ -1233,8 +1220,8 @@ __device__ __forceinline__ void replay_burst_chunked(unsigned long long &act, ui
       [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e), [pl] "=&v"(pl), [grp] "=&v"(grp), [pos] "=&v"(pos),    \
       [lim] "=&v"(lim)
 #define CB_CHUNKED_INPUTS                                                                                        \
-  [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [minx2] "s"(minx2), [miny2] "s"(miny2), [sx] "s"(sx),        \
-      [sy] "s"(sy), [w] "s"(w), [h] "s"(h), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),            \
+  [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx),                                             \
+      [sy] "s"(sy), [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16), [rsh] "s"(row_shift),            \
       [tag] "v"(tag), [emit] "s"(emit), [tlx] "s"(tlx), [tly] "s"(tly), [chs] "s"(chs), [gcl] "s"(cursors_lds),  \
       [one] "v"(1u)
   const double rx = kPow2 ? 0.0 : ka->rcp_delta_real, ry = kPow2 ? 0.0 : ka->rcp_delta_imag;
