@@ -414,7 +414,7 @@ def main():
                 "samples_per_step_per_gpu": threads * samples_per_thread,
                 "passes_per_step": PASSES_PER_STEP,
                 "histogram": "u64, one private full-resolution copy per GPU, one RCCL reduce after the timed region",
-                "scatter": ("deferred: pixel stream -> counting sort by 128x128 tile -> LDS accumulate -> coalesced "
+                "scatter": ("deferred: pixel stream -> region-local sorts by 128x128 tile -> gather into LDS tiles -> coalesced "
                             "flush (%.1f GiB workspace)" % (ws_bytes / 2.0 ** 30)) if ws_bytes
                            else "direct device-scope u64 atomics",
                 "parallelism": "sample-sharded by RNG subsequence x%d" % world,

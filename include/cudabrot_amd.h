@@ -153,7 +153,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
 size_t cb_carry_bytes(uint32_t n_threads);
 
 /* Second half of the scatter: partitions the pixel stream a cb_draw_buddhabrot call left in
- * d_workspace by 128x128-pixel tile (counting sort) and adds every tile to d_hist from an LDS
+ * d_workspace by 128x128-pixel tile (sorts of regions of 32768 entries) and adds every tile to d_hist from an LDS
  * histogram with coalesced atomics.  Same dims, n_threads, d_workspace and workspace_bytes as that
  * call.  A no-op for a workspace the draw call could not use.  Precondition: the workspace was last written by
  * a cb_draw_buddhabrot call with these arguments (a call that launches nothing -- no samples, nothing to
