@@ -45,7 +45,7 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6   # MI355X: 256 CU x 4 SIMD x 16 lanes x 2 flop x
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOPS_PER_ITERATION = 10         # 6 mul + 4 add/sub of cudabrot.cu:331-336
 ISSUE_SLOTS_PER_ITERATION = 7    # a tested step: 6 fp64 instructions (doubled-coordinate step) + 1 compare (HEAD, MID, REPLAY)
-LONG_SLOTS_PER_ITERATION = 4.3   # the LONG stage tests for escape on every tenth step: 4 + 3/10 instructions per step
+LONG_SLOTS_PER_ITERATION = 4.1   # the LONG stage tests for escape once per chunk of 60: (60 * 8 + 12) / 120 instructions per step
 PRACTICAL_HBM_GBPS = 6290.0      # MI355X_MICROARCH.md: measured float4 copy, the achievable streaming rate
 BYTES_PER_INCREMENT = 16         # u64 read + write per histogram increment
 
@@ -162,7 +162,7 @@ def full_iterate_leg(cb, torch, np, dims, it, hist, states, counters, threads, s
         "peak": PEAK_FP64_VECTOR_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
-        # ~97 % of this variant's iterations are LONG-stage steps (4.3 instructions), the rest tested steps (7)
+        # ~97 % of this variant's iterations are LONG-stage steps (4.1 instructions), the rest tested steps (7)
         "issue_frac": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
                             / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
         "avg_launch_ms": round(fms, 4),

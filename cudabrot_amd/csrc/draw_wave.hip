@@ -662,6 +662,36 @@ constexpr double kSparseThreshold = 16.0 - 0x1p-10;
   "v_cmp_le_f64_e64 %[c0], %[a0], %[kt]\n\t"              \
   "v_cmp_le_f64_e64 %[c1], %[a1], %[kt]\n\t"
 #define CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT CB_STEP2_NT
+// ---- ... and on the LAST step only --------------------------------------------------------------------
+//
+// (-DCB_SPARSE_STRIDE=10 keeps the form above.)  The tenth-step tests exist because the bound above is weak where
+// |C| may exceed 4 by a rounding: there an orbit just beyond |Z| = 4 need not move away from it.  For a sample
+// with |C|^2 < 16 - 2^-10 (|C| < 4 - 2^-13) it must: |Z| > 4 implies |Z'| >= |Z|^2 / 2 - |C| > 4 + 2^-13,
+// against a rounding of 2^-44 per step -- once the reference's test has fired, every later |Z|^2 is above 16
+// (or infinite, or NaN: `nle` is true for NaN).  So for such a sample ONE test, behind the chunk's last step, is
+// the exact answer to "did it escape inside the chunk": !(M_last <= 16), M_last being the very expression the
+// reference tests.  The other samples -- |c| within 2^-14 of 2, and of those only what has survived HEAD and
+// MID: about one in 10^8 -- are decided by verify_chunk_escape at every chunk they run.  The class of a sample
+// is recomputed with the chunk (3 instructions per orbit set: cheaper than a flag that lives across chunks).
+// 8 instructions per step for the two orbits + 12 per chunk: 492 per 60 steps instead of 516.
+#ifndef CB_SPARSE_STRIDE
+#define CB_SPARSE_STRIDE 0
+#endif
+#define CB_STEP2_LAST_TEST                                \
+  "v_mul_f64 %[a0], %[ra], %[ra]\n\t"                     \
+  "v_mul_f64 %[a1], %[rb], %[rb]\n\t"                     \
+  "v_fma_f64 %[a0], %[ia], %[ia], %[a0]\n\t"              \
+  "v_fma_f64 %[a1], %[ib], %[ib], %[a1]\n\t"              \
+  "v_cmp_nle_f64_e64 %[d0], %[a0], %[k16]\n\t"            \
+  "v_cmp_nle_f64_e64 %[d1], %[a1], %[k16]\n\t"            \
+  "v_mul_f64 %[a0], %[cra], %[cra]\n\t"                   \
+  "v_mul_f64 %[a1], %[crb], %[crb]\n\t"                   \
+  "v_fma_f64 %[a0], %[cia], %[cia], %[a0]\n\t"            \
+  "v_fma_f64 %[a1], %[cib], %[cib], %[a1]\n\t"            \
+  "v_cmp_nlt_f64_e64 %[c0], %[a0], %[kt]\n\t"             \
+  "v_cmp_nlt_f64_e64 %[c1], %[a1], %[kt]\n\t"
+#define CB_STEP2_NTX10 CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_NT
+#define CB_STEP2_NTX30 CB_STEP2_NTX10 CB_STEP2_NTX10 CB_STEP2_NTX10
 constexpr int kSparseStride = 10;  // steps between tests; the bound above is for at most ten
 #define CB_SPARSE_GROUP_FIRST CB_STEP2_NT CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
 #define CB_SPARSE_GROUP_NEXT CB_STEP2_NT_AND CB_STEP2_NTX8 CB_STEP2_NT CB_STEP2_TEST
@@ -692,6 +722,34 @@ __device__ __forceinline__ void iterate_chunk2_sparse(unsigned long long mask_a,
   unsigned long long la = mask_a, lb = mask_b, c0, c1, d0, d1;
   double a0, a1;
   const double k16 = 16.0, kt = threshold;  // kSparseThreshold, or a test's lower one (DrawArgs::sparse_threshold)
+#if CB_SPARSE_STRIDE == 0
+  // one test behind the last step: esc = escaped (exact for the lanes of sure); sure = |C|^2 below the threshold
+  static_assert(kChunk == 30 || kChunk == 60 || kChunk == 90 || kChunk == 120, "unrolled in thirties");
+  asm volatile(
+      CB_STEP2_NTX30
+#if CB_CHUNK >= 60
+      CB_STEP2_NTX30
+#endif
+#if CB_CHUNK >= 90
+      CB_STEP2_NTX30
+#endif
+#if CB_CHUNK >= 120
+      CB_STEP2_NTX30
+#endif
+      CB_STEP2_LAST_TEST
+      "s_nop 2\n\t"
+      : [ra] "+v"(oa.r), [ia] "+v"(oa.i), [rb] "+v"(ob.r), [ib] "+v"(ob.i), [a0] "=&v"(a0), [a1] "=&v"(a1),
+        [c0] "=&s"(c0), [c1] "=&s"(c1), [d0] "=&s"(d0), [d1] "=&s"(d1)
+      : [cra] "v"(oa.cr), [cia] "v"(oa.ci), [crb] "v"(ob.cr), [cib] "v"(ob.ci), [k16] "s"(k16), [kt] "s"(kt)
+      : "scc");
+  (void) la;
+  (void) lb;
+  // the caller decides esc & ~sure exactly: make that "every lane that is not sure" (escaped or not at the end)
+  esc_a = mask_a & (d0 | c0);
+  esc_b = mask_b & (d1 | c1);
+  sure_a = ~c0;
+  sure_b = ~c1;
+#else
   asm volatile(
       CB_SPARSE_CHUNK
       "v_cmp_nle_f64_e64 %[d0], %[a0], %[k16]\n\t"
@@ -708,6 +766,7 @@ __device__ __forceinline__ void iterate_chunk2_sparse(unsigned long long mask_a,
   esc_b = mask_b & ~lb;
   sure_a = d0;
   sure_b = d1;
+#endif
 }
 
 // The exact decision for the lanes of `doubt`: did the orbit with starting point (cr, ci) escape during the
