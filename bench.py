@@ -446,8 +446,8 @@ def main():
                         "found exactly periodic are retired early with the identical outcome, so at max_iter=20000 only "
                         "~13 % of the reference's iterations are executed).  The kernel spends fewer fp64 instructions than "
                         "that on most of them: a tested step is 6 fp64 instructions + 1 compare (doubled-coordinate form), "
-                        "and the LONG stage -- escape is absorbing, so it tests every tenth step and decides the rare "
-                        "doubtful lane exactly -- 4.3 per step; it also draws, tests and replays, so `frac` is neither a "
+                        "and the LONG stage -- escape is absorbing, so it tests once per chunk of 60 steps and decides the rare "
+                        "sample with |c| next to 2 exactly -- 4.1 per step; it also draws, tests and replays, so `frac` is neither a "
                         "ceiling-bounded utilisation nor comparable with round 1's (which issued 7 per step everywhere).  "
                         "avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the previous "
                         "launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, before the "
