@@ -293,8 +293,7 @@ __device__ __forceinline__ uint32_t sort_word(uint32_t e, uint32_t k0, const Bin
 // kChunked (BinLayout::chunked): the region is a list of at most kRegionChunks chunks of the stream (region_start:
 // first entry of chunk_list, region_count: chunks) instead of a stretch of it; its image goes to sorted[r * 32768]
 // and region_count[r] becomes its number of entries, which is what the gather reads.
-// kSkipFull: the regions that bin_region_sort_full_kernel (below) has sorted are left alone.
-template <bool kPlain, bool kFewTiles, bool kChunked = false, bool kSkipFull = false>
+template <bool kPlain, bool kFewTiles, bool kChunked = false>
 __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b) {
   constexpr uint32_t kCntReplicas = SortLds<kFewTiles>::kReplicas, kCntStride = SortLds<kFewTiles>::kStride;
   constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
@@ -312,7 +311,6 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
   uint32_t n = kChunked ? 0u : b.region_count[r];
   const unsigned long long start = kChunked ? (unsigned long long) r * kRegionEntries : b.region_start[r];
-  if (kSkipFull && n == kRegionEntries && (start & 3ull) == 0ull) continue;
   const uint32_t *src = kChunked ? b.stream : (b.two_level ? b.grouped : b.stream) + start;
   const uint32_t k0 = b.region_group[r] << kGroupShift;
   const uint32_t nk = (b.n_tiles - k0) < kGroupTiles ? (b.n_tiles - k0) : kGroupTiles;
@@ -454,123 +452,6 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   }
   if (kChunked && threadIdx.x == 0) b.region_count[r] = n;  // from chunks to entries (every region is sorted once)
   }  // regions of this workgroup
-}
-
-// ---- region sort, FULL regions of a one-level plain stream (C2 / C3) ------------------------------------
-//
-// Ten of a wave's eleven regions in a steady launch are full: 32768 entries from a 16-byte boundary.  They need
-// neither the validity masks nor the dummy key, and what is left per entry is little enough to write down: the
-// compiler's kernel issues ~28 vector instructions per entry (and spills when given this simpler job, as a branch
-// or as an instance of its own), these two asm statements 8 + 3.  Steps and LDS layout as above (two counter
-// replicas); only full regions are taken, bin_region_sort_kernel<.., kSkipFull> takes the others afterwards.
-//
-// CB_SORT_WORD: the stream word e = row << 16 | col in place -> (tile << 16) | in-tile offset, and one count.
-//   tile = (row >> 7) * tiles_x + (col >> 7); offset = (row & 127) << 7 | (col & 127)
-#define CB_SORT_WORD(e)                                   \
-  "v_lshrrev_b32 %[t], 23, " e "\n\t"                     \
-  "v_bfe_u32 %[u], " e ", 7, 9\n\t"                       \
-  "v_mad_u32_u24 %[t], %[t], %[tlx], %[u]\n\t"            \
-  "v_and_b32 %[u], 0x7f, " e "\n\t"                       \
-  "v_bfe_u32 %[w], " e ", 16, 7\n\t"                      \
-  "v_lshl_or_b32 %[u], %[w], 7, %[u]\n\t"                 \
-  "v_lshl_or_b32 " e ", %[t], 16, %[u]\n\t"               \
-  "v_lshl_add_u32 %[t], %[t], 2, %[cb]\n\t"               \
-  "ds_add_u32 %[t], %[one]\n\t"
-// eight words (two 16-byte loads) at a time
-__device__ __forceinline__ void sort_words8(uint4 &a, uint4 &c, uint32_t tiles_x, uint32_t cnt_lds) {
-  uint32_t t, u, w;
-  asm volatile(CB_SORT_WORD("%[e0]") CB_SORT_WORD("%[e1]") CB_SORT_WORD("%[e2]") CB_SORT_WORD("%[e3]")
-               CB_SORT_WORD("%[e4]") CB_SORT_WORD("%[e5]") CB_SORT_WORD("%[e6]") CB_SORT_WORD("%[e7]")
-               : [e0] "+v"(a.x), [e1] "+v"(a.y), [e2] "+v"(a.z), [e3] "+v"(a.w), [e4] "+v"(c.x), [e5] "+v"(c.y),
-                 [e6] "+v"(c.z), [e7] "+v"(c.w), [t] "=&v"(t), [u] "=&v"(u), [w] "=&v"(w)
-               : [tlx] "s"(tiles_x), [cb] "v"(cnt_lds), [one] "v"(1u)
-               : "memory");
-}
-// rank and place eight entries: pos = counter++ (the eight returning adds in flight together), then
-// image[pos] = low half of the word; ib: LDS byte address of image[shift]
-#define CB_RANK(p, e)                                     \
-  "v_lshrrev_b32 " p ", 16, " e "\n\t"                    \
-  "v_lshl_add_u32 " p ", " p ", 2, %[cb]\n\t"             \
-  "ds_add_rtn_u32 " p ", " p ", %[one]\n\t"
-#define CB_PLACE(n, p, e)                                 \
-  "s_waitcnt lgkmcnt(" n ")\n\t"                          \
-  "v_lshl_add_u32 " p ", " p ", 1, %[ib]\n\t"             \
-  "ds_write_b16 " p ", " e "\n\t"
-__device__ __forceinline__ void place_words8(const uint4 &a, const uint4 &c, uint32_t cnt_lds, uint32_t image_lds) {
-  uint32_t p0, p1, p2, p3, p4, p5, p6, p7;
-  // (the writes queue up behind the adds: when the wait for add k lets go, 7 - k adds and k writes are outstanding)
-  asm volatile(CB_RANK("%[p0]", "%[e0]") CB_RANK("%[p1]", "%[e1]") CB_RANK("%[p2]", "%[e2]") CB_RANK("%[p3]", "%[e3]")
-               CB_RANK("%[p4]", "%[e4]") CB_RANK("%[p5]", "%[e5]") CB_RANK("%[p6]", "%[e6]") CB_RANK("%[p7]", "%[e7]")
-               CB_PLACE("7", "%[p0]", "%[e0]") CB_PLACE("7", "%[p1]", "%[e1]") CB_PLACE("7", "%[p2]", "%[e2]")
-               CB_PLACE("7", "%[p3]", "%[e3]") CB_PLACE("7", "%[p4]", "%[e4]") CB_PLACE("7", "%[p5]", "%[e5]")
-               CB_PLACE("7", "%[p6]", "%[e6]") CB_PLACE("7", "%[p7]", "%[e7]")
-               : [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3), [p4] "=&v"(p4), [p5] "=&v"(p5),
-                 [p6] "=&v"(p6), [p7] "=&v"(p7)
-               : [e0] "v"(a.x), [e1] "v"(a.y), [e2] "v"(a.z), [e3] "v"(a.w), [e4] "v"(c.x), [e5] "v"(c.y), [e6] "v"(c.z),
-                 [e7] "v"(c.w), [cb] "v"(cnt_lds), [ib] "v"(image_lds), [one] "v"(1u)
-               : "memory");
-}
-
-__global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_full_kernel(BinLayout b) {
-  constexpr uint32_t kCntReplicas = SortLds<false>::kReplicas, kCntStride = SortLds<false>::kStride;
-  extern __shared__ uint32_t lds[];
-  uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
-  uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
-  uint16_t *image = reinterpret_cast<uint16_t *>(lds + kCntReplicas * kCntStride + 16 + 2 * kRegionChunks + 4);
-  const uint32_t cnt_lds = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(cnt));
-  const uint32_t n_regions = *b.n_regions;
-  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
-    const unsigned long long start = b.region_start[r];
-    if (b.region_count[r] != kRegionEntries || (start & 3ull) != 0ull) continue;  // (wave-uniform)
-    const uint4 *src4 = reinterpret_cast<const uint4 *>(b.stream + start);
-    __syncthreads();  // (a further region of this workgroup: the previous image has left)
-    for (uint32_t t = threadIdx.x; t < kCntReplicas * kCntStride; t += kSortThreads) lds[t] = 0u;
-    __syncthreads();
-    // 1. the entries, once, 32 per thread: tile and in-tile offset, counted per tile (two batches of four loads)
-    uint4 v[kSortPerThread / 4u];
-#pragma unroll
-    for (uint32_t half = 0; half < 2; ++half) {
-#pragma unroll
-      for (uint32_t j = 0; j < 4; ++j) v[half * 4u + j] = src4[(half * 4u + j) * kSortThreads + threadIdx.x];
-      sort_words8(v[half * 4u], v[half * 4u + 1u], b.tiles_x, cnt_lds);
-      sort_words8(v[half * 4u + 2u], v[half * 4u + 3u], b.tiles_x, cnt_lds);
-    }
-    __syncthreads();
-    // 2. where each tile's run starts (as in bin_region_sort_kernel; all 1024 keys are real, group 0)
-    {
-      uint32_t c[kCntReplicas], sum = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < kCntReplicas; ++k) {
-        c[k] = lds[k * kCntStride + threadIdx.x];
-        sum += c[k];
-      }
-      uint32_t total = 0;
-      uint32_t first = block_exclusive_scan(sum, wave_totals, &total);
-      __syncthreads();  // every count has been read
-      if (threadIdx.x < b.n_tiles) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
-#pragma unroll
-      for (uint32_t k = 0; k < kCntReplicas; ++k) {
-        lds[k * kCntStride + threadIdx.x] = first;
-        first += c[k];
-      }
-    }
-    __syncthreads();
-    // 3. rank and place
-    const uint32_t shift = (uint32_t) (start & 7ull);
-    const uint32_t image_lds = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(image + shift));
-#pragma unroll
-    for (uint32_t q = 0; q < kSortPerThread / 8u; ++q) place_words8(v[2u * q], v[2u * q + 1u], cnt_lds, image_lds);
-    __syncthreads();
-    // 4. the image leaves as one linear block (shift is 0 or 4: the block starts and ends on 8-byte boundaries at worst)
-    uint16_t *dst = b.sorted + (start - shift);
-    const uint32_t lo = shift, hi = shift + kRegionEntries;
-    const uint32_t body_lo = (lo + 7u) & ~7u, body_hi = hi & ~7u;
-    for (uint32_t i = lo + threadIdx.x; i < body_lo; i += kSortThreads) dst[i] = image[i];
-    const uint4 *s4 = reinterpret_cast<const uint4 *>(image);
-    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-    for (uint32_t i = (body_lo >> 3) + threadIdx.x; i < (body_hi >> 3); i += kSortThreads) d4[i] = s4[i];
-    for (uint32_t i = body_hi + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
-  }
 }
 
 // ---- gather + accumulate ---------------------------------------------------------------------------
@@ -1099,10 +980,6 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   } else if (few) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, true>, SortLds<true>::kBytes);
-  } else if (plain && !b.two_level && b.n_tiles == kGroupTiles && getenv("CUDABROT_AMD_NO_FULL_SORT") == nullptr) {
-    // C2 / C3 (exactly 1024 tiles): the full regions by the asm kernel, the others by the general one
-    se = launch_sort(bin_region_sort_full_kernel, SortLds<false>::kBytes);
-    if (se == hipSuccess) se = launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes);
   } else {
     se = plain ? launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, false>, SortLds<false>::kBytes);
