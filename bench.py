@@ -471,8 +471,8 @@ def main():
                         "of the scatter kernels run alone (two launches before the clock); pipelined_ms is their "
                         "event-to-event time inside the timed region, where they share the GPU with the next "
                         "draw launch; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale).  `traffic` "
-                        "(fabric bytes, PMC) is what HBM sees: ~15 GB per launch, 4.4 TB/s -- the kernels are held by "
-                        "their LDS atomics more than by HBM (on a quarter of the CUs they take 3.3 x as long, DESIGN.md 7)",
+                        "(fabric bytes, PMC) is what HBM sees: ~15 GB per launch, 4.4 TB/s over the whole scatter, 4.8-5.2 TB/s "
+                        "in the region sort -- 0.8 of the 6.29 TB/s a float4 copy reaches (DESIGN.md 7)",
             },
         }
         if full_iterate is not None:

@@ -268,7 +268,10 @@ constexpr uint32_t kDummyPlace = kRegionEntries + 8u;
 // (the reference's default 1000 x 1000 has 64) -- eight replicas of 256.
 template <bool kFewTiles>
 struct SortLds {
-  static constexpr uint32_t kReplicas = kFewTiles ? 8u : 2u;
+#ifndef CB_CNT_REPLICAS
+#define CB_CNT_REPLICAS 2
+#endif
+  static constexpr uint32_t kReplicas = kFewTiles ? 8u : CB_CNT_REPLICAS;
   static constexpr uint32_t kStride = (kFewTiles ? 256u : kGroupTiles) + 16u;  // counters of a replica + the dummy
   static constexpr size_t kBytes =  // counters | wave_totals[16] | chunks of the region[32] {first word, words} | image
       (kReplicas * kStride + 16 + 2 * kRegionChunks + 4) * sizeof(uint32_t) + (kRegionEntries + 16) * sizeof(uint16_t);
