@@ -57,6 +57,7 @@ def trial(rng):
     t["seed"] = rng.choice([1337, 1337, 1, 0xdeadbeefcafe])
     t["first"] = rng.choice([0, 0, 1, 262144, 2097151])
     t["two_level"] = rng.random() < 0.2          # the large-canvas sort on any canvas (test knob)
+    t["chunked"] = rng.random() < 0.7            # ... its level A by the draw kernel (chunked stream) or as a counting sort
     t["windows"] = None
     if rng.random() < 0.25:                      # fused multi-channel launch: plane j == a run with window j
         t["windows"] = [(rng.choice([30, 100, 400, 2500]), rng.choice([0, 5, 20, 50, 300])) for _ in range(rng.randint(1, 4))]
@@ -83,6 +84,7 @@ def render(t, variant, window=None, fused=False, on_device=False):
         os.environ["CUDABROT_AMD_TWO_LEVEL"] = "1"
     else:
         os.environ.pop("CUDABROT_AMD_TWO_LEVEL", None)
+    os.environ["CUDABROT_AMD_CHUNKED"] = "1" if t.get("chunked", True) else "0"
     ws_bytes = 0
     if not simple and t["workspace"] != "none":
         ws_bytes = cb.scatter_workspace_bytes(dims, n, max(t["launch_samples"]), n_channels=max(planes, 1))
@@ -156,7 +158,8 @@ def renderer_trial(rng):
 
 def render_with_renderer(t):
     for k, v in (("CUDABROT_AMD_PASSES_PER_LAUNCH", t["per_launch"]), ("CUDABROT_AMD_NO_WORKSPACE", 1 if t["no_workspace"] else None),
-                 ("CUDABROT_AMD_TWO_LEVEL", 1 if t["two_level"] else None)):
+                 ("CUDABROT_AMD_TWO_LEVEL", 1 if t["two_level"] else None),
+                 ("CUDABROT_AMD_CHUNKED", 1 if t.get("chunked", True) else 0)):
         if v is None:
             os.environ.pop(k, None)
         else:
