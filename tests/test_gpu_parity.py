@@ -314,6 +314,23 @@ def test_canvas_beyond_4096_tiles_uses_two_levels(cb, oracle, monkeypatch, chunk
     assert_same(got, cpu)
 
 
+@pytest.mark.parametrize("variant_name", ["CB_KERNEL_TIMED", "CB_KERNEL_FULL_ITERATE"])
+def test_other_kernel_instances_on_a_chunked_stream(cb, oracle, monkeypatch, variant_name):
+    """The timed and the full-iterate instances of the draw kernel write the chunked stream too (a workspace is
+    chunked or not by its canvas alone, whichever kernel variant fills it)."""
+    monkeypatch.setenv("CUDABROT_AMD_TWO_LEVEL", "1")
+    w, h, t, passes = 1300, 900, 8192, 3
+    dims = cb.FractalDimensions.make(w, h)
+    with cb.Renderer(dims, cb.IterationControl(600, 20), n_threads=t) as r:
+        r.render_passes(passes, getattr(cb, variant_name))
+        got = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    ref, rc = oracle.render(w, h, 600, 20, t, passes)
+    assert cnt["status"] == 0
+    assert np.array_equal(got, ref)
+    assert cnt["increments"] == rc["increments"] and cnt["samples"] == rc["samples"]
+
+
 @pytest.mark.parametrize("fraction", [0.3, 0.6, 0.8])
 def test_chunked_stream_that_runs_out_of_chunks(cb, oracle, fraction):
     """Five groups, and a workspace smaller than the launch needs: a wave that has not enough free chunks left for
