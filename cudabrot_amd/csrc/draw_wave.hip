@@ -132,6 +132,9 @@ struct WaveQueues {
   double q0_cr[kQ0Cap], q0_ci[kQ0Cap];
   double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];
   double q2_cr[kQ2Cap], q2_ci[kQ2Cap];
+  // iterations the orbit had left when the LONG chunk in which it escaped began (so its escape index lies in
+  // [max_iter - q2_lrem, + kChunk)); 0: not known (accepted in another stage, or in its exact tail chunk)
+  uint32_t q2_lrem[kQ2Cap];
 };
 
 struct Orbit {
@@ -893,6 +896,7 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "s_mov_b64 exec, %[esc]\n\t"  \
       "s_cbranch_execz 1f\n\t"  \
       "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem]\n\t"  \
+      "v_mov_b32 %[lr], %[lrem]\n\t"  \
       "v_mov_b32 %[lrem], 0\n\t"  \
       "s_mov_b64 %[push], vcc\n\t"  \
       "s_mov_b64 exec, vcc\n\t"  \
@@ -902,7 +906,9 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "v_add_u32 %[slot], %[tail2], %[slot]\n\t"  \
       "v_subrev_u32 %[t], 192, %[slot]\n\t"  \
       "v_min_u32 %[slot], %[slot], %[t]\n\t"  \
+      "v_lshl_add_u32 %[t], %[slot], 2, %[q2]\n\t"  \
       "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"  \
+      "ds_write_b32 %[t], %[lr] offset:3072\n\t"  /* q2_lrem: what the orbit had left at the start of this chunk */ \
       "ds_write_b64 %[slot], %[cr]\n\t"  \
       "ds_write_b64 %[slot], %[ci] offset:1536\n\t"  \
       "1:\n\t"  \
@@ -929,10 +935,10 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
                                             uint32_t check_periodic, uint32_t q2_tail, uint32_t q2_lds,
                                             unsigned long long &push, unsigned long long &ended,
                                             unsigned long long &periodic) {
-  static_assert(kQ2Cap == 192, "ring length and plane distance below");
+  static_assert(kQ2Cap == 192, "ring length and plane distances below (q2_ci 1536, q2_lrem 3072 bytes on)");
   static_assert(kBrentBits >= 1 && kBrentBits <= 8, "bits of the chunk count kept by the save schedule");
   unsigned long long save;
-  uint32_t slot, t;
+  uint32_t slot, t, lr;
   // chunks done = steps done / kChunk, exactly, as a float (a few thousand at most): the count has no set
   // bit below its top kBrentBits iff the float's mantissa is zero below its top kBrentBits - 1 bits
   const float inv_chunk = 1.0f / (float) kChunk;
@@ -940,7 +946,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
 #define CB_RETIRE_OPERANDS                                                                                   \
   : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),      \
     [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic), [save] "=&s"(save), [slot] "=&v"(slot), \
-    [t] "=&v"(t)                                                                                             \
+    [t] "=&v"(t), [lr] "=&v"(lr)                                                                             \
   : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),       \
     [chkf] "s"(check_periodic), [invl] "s"(inv_chunk), [kmask] "s"(low_mantissa),                            \
     [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)                             \
@@ -1436,6 +1442,10 @@ draw_wave_kernel(DrawArgs a) {
   const bool multi = a.n_channels > 0;
   bool p_real = true;
   uint32_t p_tag = 0u;
+  // p_direct: this orbit's channels were known from the chunk it escaped in (q2_lrem), so its first pass already
+  // records; what the measuring pass would have settled (the over-count of its last LONG chunk) is settled at
+  // the end of that pass
+  bool p_direct = false;
   // lanes of `finished` have just ended a replay pass: the measuring one (then the orbit's channels are
   // known) or a recorded one (then the next of its channels follows, if any -- windows may overlap)
   auto channel_decision = [&](unsigned long long finished) {
@@ -1449,7 +1459,8 @@ draw_wave_kernel(DrawArgs a) {
       if (p_real) set &= ~((2u << (p_tag >> a.bin.e_chan_shift)) - 1u);  // the channels still to come
     }
     const bool measured = fin && !p_real;
-    if (measured && a.sparse_long) over += long_overcount(p_steps, a.long_start, a.tail_start);
+    if ((measured || (fin && p_direct)) && a.sparse_long) over += long_overcount(p_steps, a.long_start, a.tail_start);
+    if (fin) p_direct = false;
     n_recorded += (unsigned long long) __popcll(__ballot(measured && set != 0u));
     n_too_fast += (unsigned long long) __popcll(__ballot(measured && set == 0u));  // in no window (cudabrot.cu:407-408 for every channel)
     if (fin && set != 0u) {  // another pass: the same orbit from z = c, recorded into its next channel
@@ -1535,7 +1546,8 @@ draw_wave_kernel(DrawArgs a) {
     p_steps = (int) (uint32_t) pl[17 * 64];
     p_act = (pl[17 * 64] >> 32) != 0ull;
     p_tag = (uint32_t) pl[18 * 64];
-    p_real = (pl[18 * 64] >> 32) != 0ull;
+    p_real = ((pl[18 * 64] >> 32) & 1ull) != 0ull;
+    p_direct = ((pl[18 * 64] >> 33) & 1ull) != 0ull;
   }
 
   for (;;) {
@@ -1557,6 +1569,7 @@ draw_wave_kernel(DrawArgs a) {
           const int n = n_idle < q2_count ? n_idle : q2_count;
           if (n > 0) {
             const int rank = mask_prefix(idle_mask);
+            bool took_direct = false;
             if (!p_act && rank < n) {
               const int slot = q2_wrap(q2_head + rank);
               po.cr = q.q2_cr[slot];
@@ -1567,10 +1580,31 @@ draw_wave_kernel(DrawArgs a) {
               p_act = true;
               p_real = !multi;  // fused channels: first pass measures the escape index, nothing is recorded
               p_tag = 0u;
+              p_direct = false;
+              if (multi) {
+                // ... unless the chunk the orbit escaped in lies inside one set of windows: then its channels are
+                // known and the first pass records into the lowest of them (half the replay steps of such an orbit)
+                const uint32_t lr = q.q2_lrem[slot];
+                const int k_lo = max_iter - (int) lr, k_hi = k_lo + kChunk - 1;
+                uint32_t set = 0u;
+                bool known = lr != 0u;
+                for (int j = 0; j < a.n_channels; ++j) {
+                  const int lo_edge = a.chan_min[j], hi_edge = a.chan_max[j];
+                  if ((lo_edge > k_lo && lo_edge <= k_hi) || (hi_edge > k_lo && hi_edge <= k_hi)) known = false;
+                  if (k_lo >= lo_edge && k_lo < hi_edge) set |= 1u << j;
+                }
+                if (known && set != 0u) {  // (in no window: still measured -- the iteration count wants its index)
+                  p_real = true;
+                  p_direct = true;
+                  took_direct = true;
+                  p_tag = (uint32_t) (__ffs((int) set) - 1) << a.bin.e_chan_shift;
+                }
+              }
             }
             q2_head = q2_wrap(q2_head + n);
             q2_count -= n;
             if (!multi) n_recorded += (unsigned long long) n;
+            if (multi) n_recorded += (unsigned long long) __popcll(__ballot(took_direct));  // (a measured orbit is counted when its index is known)
           }
         }
         const int n_act = __popcll(__ballot(p_act));
@@ -1722,6 +1756,7 @@ draw_wave_kernel(DrawArgs a) {
           const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(accept_mask));
           q.q2_cr[slot] = o.cr;
           q.q2_ci[slot] = o.ci;
+          q.q2_lrem[slot] = 0u;
         }
         q2_count += __popcll(accept_mask);
         if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
@@ -1788,6 +1823,7 @@ draw_wave_kernel(DrawArgs a) {
           const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(accept_mask));
           q.q2_cr[slot] = o.cr;
           q.q2_ci[slot] = o.ci;
+          q.q2_lrem[slot] = 0u;
         }
         q2_count += __popcll(accept_mask);
         if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
@@ -1874,6 +1910,7 @@ draw_wave_kernel(DrawArgs a) {
                 const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(push_mask));
                 q.q2_cr[slot] = lo[o].cr;
                 q.q2_ci[slot] = lo[o].ci;
+                q.q2_lrem[slot] = 0u;
               }
               q2_count += __popcll(push_mask);
               if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
@@ -1988,7 +2025,8 @@ draw_wave_kernel(DrawArgs a) {
     pl[15 * 64] = (unsigned long long) __double_as_longlong(po.i);
     pl[16 * 64] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
     pl[17 * 64] = (unsigned long long) (uint32_t) p_steps | ((unsigned long long) (p_act ? 1u : 0u) << 32);
-    pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32);
+    pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32) |
+                  ((unsigned long long) (p_direct ? 1u : 0u) << 33);
   }
   const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
   const unsigned long long over_total = wave_sum((unsigned long long) over);

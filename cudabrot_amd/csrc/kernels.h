@@ -167,7 +167,7 @@ struct DrawArgs {
 };
 
 constexpr uint32_t kCarryHeaderWords = 8;
-constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 96 + 2 * 192);  // = sizeof(WaveQueues) / 8
+constexpr uint32_t kCarryQueueWords = (2 * 128 + 4 * 96 + 2 * 192 + 192 / 2);  // = sizeof(WaveQueues) / 8
 constexpr uint32_t kCarryLanePlanes = 19;
 constexpr uint32_t kCarryWordsPerWave = kCarryHeaderWords + kCarryQueueWords + kCarryLanePlanes * 64;
 // Behind the per-wave records of a carry buffer: the progress board of the draw kernel's waves, 16 words
