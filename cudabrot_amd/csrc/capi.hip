@@ -139,7 +139,11 @@ int empty_stream_if_nothing_launches(const cb::DrawArgs &a, hipStream_t stream) 
 // Stream entries a launch is expected to produce: visited in-canvas points per sample are 0.4 (max_iter
 // 100) to 1.7 (max_iter 20000) on the full canvas; anything beyond the estimate falls back to atomics.
 constexpr double kEntriesPerSample = 2.5;
-constexpr uint32_t kRendererPassesPerLaunch = 64;
+// Passes fused into one launch by cb_renderer.  A launch has fixed costs (the scatter's table kernels, the seams
+// of the pipeline, the spread of the waves' end times): 128 instead of 64 is + 6 % on the reference's default
+// canvas, + 7 % at max_iter 2000, + 2.5 % at 20000 (4096^2), + 0.5 % at 20000^2; 256 would not fit the stream's
+// 32-bit entry indices.  Costs workspace: 2 x 23.7 GiB at 4096^2.
+constexpr uint32_t kRendererPassesPerLaunch = 128;
 
 }  // namespace
 
@@ -499,7 +503,7 @@ int cb_renderer_create_channels(cb_renderer **out, int device, const cb_fractal_
 
 namespace {
 
-// 50 samples per thread per reference pass (cudabrot.cu:34,390), at most 64 passes per launch.
+// 50 samples per thread per reference pass (cudabrot.cu:34,390), at most kRendererPassesPerLaunch passes per launch.
 uint32_t max_passes_per_launch() {
   static const uint32_t v = [] {
     const char *e = getenv("CUDABROT_AMD_PASSES_PER_LAUNCH");  // experiment knob

@@ -487,7 +487,7 @@ class Run {
       next = per_pass > 0 ? (long) (budget / per_pass) : next * 2;
       if (next < 1) next = 1;
       if (next > 4096) next = 4096;
-      if (next > 64) next -= next % 64;  // whole launches of 64 passes: a short launch drains badly
+      if (next > 128) next -= next % 128;  // whole launches of 128 passes (cb_renderer's): a short launch drains badly
     }
     passes_this_run_ = (uint64_t) done;  // per rank: what the generators have consumed
     done *= cfg_.gpus;                   // reference-sized passes over all ranks
