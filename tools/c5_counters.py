@@ -1,3 +1,5 @@
+"""Counters per sample of the fused three-window recipe (C5) in steady launches: how many replay steps a sample costs
+(measuring passes included), python3 tools/c5_counters.py"""
 import sys, json, numpy as np, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import cudabrot_amd as cb
@@ -25,5 +27,3 @@ torch.cuda.synchronize()
 c = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
 n = c["samples"]
 print({k: round(v / n, 4) for k, v in c.items() if k in ("iterate_steps", "skipped_steps", "replay_steps", "increments", "recorded", "too_fast", "never_escaped")})
-tot = max(c["cycles_total"], 1)
-print({k: round(c[k] / tot, 3) for k in ("cycles_head", "cycles_long", "cycles_replay")})
