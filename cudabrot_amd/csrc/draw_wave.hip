@@ -151,9 +151,6 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
   return ((unsigned long long) hi << 32) | lo;
 }
-__device__ __forceinline__ double uniform_f64(double v) {
-  return __longlong_as_double((long long) uniform_u64((unsigned long long) __double_as_longlong(v)));
-}
 
 // ---- one orbit per lane under EXEC (HEAD, MID, the last short chunk of LONG) -----------------------
 //
@@ -634,7 +631,7 @@ __device__ __forceinline__ void iterate_chunk2(unsigned long long mask_a, unsign
 // and the over-count of an orbit's last chunk is taken back when REPLAY knows its escape index
 // (long_overcount).  Only used when every escape inside a full LONG chunk is accepted (min_iter <= the start
 // of the LONG stage): an escape that is too fast is never replayed, so its index would stay unknown.
-constexpr double kSparseThreshold = 16.0 - 0x1p-10;
+[[maybe_unused]] constexpr double kSparseThreshold = 16.0 - 0x1p-10;  // (the value capi.hip puts into DrawArgs::sparse_threshold)
 #define CB_STEP2_NT                                       \
   "v_mul_f64 %[a0], %[ia], %[ia]\n\t"                     \
   "v_mul_f64 %[a1], %[ib], %[ib]\n\t"                     \
