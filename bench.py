@@ -35,7 +35,15 @@ CONFIGS = {
     "C3": (4096, 4096, 20000, 20),
     "C4": (20000, 20000, 20000, 20),
     "C2": (4096, 4096, 2000, 20),
+    "C5": (20000, 15000, 60000, 20),   # fused three-window render, see C5_WINDOWS / C5_BOX
 }
+# C5: the reference's colour recipe (generate_hires_color_image.sh:27-59) as ONE fused launch -- 20000x15000 on
+# [-2,2] x [-1.5,1.5], the recipe's three (max, min) escape windows
+C5_WINDOWS = [(60000, 45000), (8000, 1000), (500, 20)]
+C5_BOX = (-2.0, 2.0, -1.5, 1.5)
+SHADER_CLOCK_SPEC_GHZ = 2.4
+N_SIMDS = 1024                   # 256 CUs x 4 SIMDs
+VALU_CYCLES_PER_INST = 4         # SQ_INSTS_VALU counts wave-instructions; a SIMD issues one per 4 cycles at best
 W = H = 4096
 MAX_ITER, MIN_ITER = 20000, 20
 THREADS = 512 * 512
@@ -76,24 +84,74 @@ def cpu_baseline(budget_s=12.0):
     }
 
 
-def recorded_traffic(samples_per_step):
-    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*_summary.json, made by tools/gpu_profile.sh + tools/summarize_profile.py) whose launch
-    size matches this run; None if there is none.  PMC passes cannot run inside this process."""
+def newest_summary(samples_per_step, workload_prefix="C3"):
+    """The newest committed rocprofv3 summary (profiles/*_summary.json, made by tools/gpu_profile.sh +
+    tools/summarize_profile.py) of THIS round's kernels whose launch size and workload match this run; None if
+    there is none.  PMC passes cannot run inside this process, so counter-derived figures come from there."""
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_summary.json"))):   # this round's kernels
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]*_summary.json"))):
         try:
             s = json.load(open(f))
-            if s["bench_line"]["config"]["samples_per_step_per_gpu"] == samples_per_step:
-                t = s["traffic_bytes_per_launch"]
-                best = {"draw": t["draw_wave_kernel"]["total"], "scatter": t["scatter_kernels"]["total"],
-                        "source": os.path.relpath(f, ROOT),
-                        "scatter_mode": s["bench_line"]["config"].get("scatter", "")[:8]}
+            cfg = s["bench_line"]["config"]
+            if cfg["samples_per_step_per_gpu"] == samples_per_step and cfg["workload"].startswith(workload_prefix):
+                best = (f, s)
         except (KeyError, TypeError, ValueError):
             continue
     return best
+
+
+def recorded_traffic(samples_per_step):
+    """HBM-side bytes per launch of the draw kernel and of the scatter kernels from that summary."""
+    best = newest_summary(samples_per_step)
+    if not best:
+        return None
+    f, s = best
+    try:
+        t = s["traffic_bytes_per_launch"]
+        draw = [k for k in t if k.startswith("draw_")][0]
+        return {"draw": t[draw]["total"], "scatter": t["scatter_kernels"]["total"],
+                "source": os.path.relpath(f, ROOT), "scatter_mode": s["bench_line"]["config"].get("scatter", "")[:8]}
+    except (KeyError, IndexError, TypeError):
+        return None
+
+
+def recorded_valu_busy(samples_per_step, kernel_prefix="draw_"):
+    """Vector-issue utilisation of the draw kernel from the counters of that summary: SQ_INSTS_VALU (wave
+    instructions per dispatch) x 4 cycles (a SIMD issues one fp64 wave-instruction per 4 cycles) over the SIMD
+    cycles of the SAME profiled dispatch (1024 SIMDs x its duration x clock) -- bounded by 1, unlike `frac`.
+    Both at the 2.4 GHz spec clock and at the clock the counters themselves give (GRBM_GUI_ACTIVE / 8 XCDs /
+    duration: MI355X_MICROARCH.md, DVFS give-back)."""
+    best = newest_summary(samples_per_step)
+    if not best:
+        return None
+    f, s = best
+    try:
+        name = [k for k in s["pmc"] if k.startswith(kernel_prefix) and s["pmc"][k]][0]
+        c = s["pmc"][name]
+        insts = c["SQ_INSTS_VALU"]["mean_per_dispatch"]
+        salu = c["SQ_INSTS_SALU"]["mean_per_dispatch"]
+        # duration of the dispatches of the SAME pass the counter came from (a profiled pass runs a few % slower)
+        by_pass = s.get("draw_dispatch_ms_by_pass", {})
+        if c["SQ_INSTS_VALU"]["pass"] in by_pass:
+            ms = by_pass[c["SQ_INSTS_VALU"]["pass"]]["median"]
+        else:
+            v = sorted(s["draw_wave_kernel_dispatch_ms"])
+            ms = v[len(v) // 2]
+        clock_ghz = c["GRBM_GUI_ACTIVE"]["mean_per_dispatch"] / 8.0 / (ms * 1e-3) / 1e9
+        busy_spec = insts * VALU_CYCLES_PER_INST / (N_SIMDS * ms * 1e-3 * SHADER_CLOCK_SPEC_GHZ * 1e9)
+        return {
+            "valu_busy": round(busy_spec, 4),
+            "valu_busy_at_measured_clock": round(busy_spec * SHADER_CLOCK_SPEC_GHZ / clock_ghz, 4),
+            "measured_clock_ghz": round(clock_ghz, 3),
+            "sq_insts_valu_per_launch": insts,
+            "sq_insts_salu_per_launch": salu,
+            "profiled_dispatch_ms": round(ms, 4),
+            "valu_busy_source": os.path.relpath(f, ROOT),
+        }
+    except (KeyError, IndexError, TypeError, ZeroDivisionError):
+        return None
 
 
 def reference_gpu(seconds=6):
@@ -122,54 +180,202 @@ def reference_gpu(seconds=6):
             pass
 
 
-def full_iterate_leg(cb, torch, np, dims, it, hist, states, counters, threads, samples_per_thread, stream, workspace,
-                     ws_bytes, dev):
+def full_iterate_leg(job, torch, np, dev):
     """The iterate loop against its roofline: the same launch with the periodicity early-out off, i.e. every sample
     iterated to max_iter as the reference does (same histogram).  Driven like the product: carry buffer, so that the
     waves pace themselves by the progress board; six launches and the drain launch that completes them, every
     executed iteration over all seven."""
-    workspaces = [workspace]
-    # the iterate loop against its roofline: the same launch with the periodicity early-out off,
-    # i.e. every sample iterated to max_iter as the reference does (same histogram)
-    # (driven like the product: carry buffer, so that the waves pace themselves by the progress board; six
-    # launches and the drain launch that completes them, every executed iteration over all seven)
-    counters.zero_()
-    fcarry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
+    cb = job.cb
+    job.counters.zero_()
+    fcarry = torch.zeros(cb.carry_bytes(job.threads), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     FULL_LAUNCHES = 6
     fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
            for _ in range(FULL_LAUNCHES + 1)]
     for n, (a, b) in enumerate(fev):
         a.record()
-        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads,
-                           samples_per_thread if n < FULL_LAUNCHES else 0, counters.data_ptr(),
-                           cb.CB_KERNEL_FULL_ITERATE,
-                           stream, workspaces[0].data_ptr() if ws_bytes else 0, ws_bytes, fcarry.data_ptr())
+        job.draw(job.samples if n < FULL_LAUNCHES else 0, 0, variant=cb.CB_KERNEL_FULL_ITERATE, carry=fcarry)
         b.record()
-        if ws_bytes:
-            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
+        job.flush(0, stream=job.stream)
     torch.cuda.synchronize()
     f_each = [a.elapsed_time(b) for a, b in fev]
     fms = sum(f_each) / FULL_LAUNCHES    # per launch of samples: the drain launch's time is shared by them
-    fc = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
+    fc = job.counter_values(np)
     fiters = (fc["iterate_steps"] - fc["skipped_steps"] + fc["replay_steps"]) / FULL_LAUNCHES
     ftf = fiters * FLOPS_PER_ITERATION / (fms * 1e-3) / 1e12
     result = {
         "bound": "valu_fp64",
-        "kernel": "draw_wave_kernel (CB_KERNEL_FULL_ITERATE: early-out off, %.1f iterations/sample executed)"
-                  % (fiters / (threads * samples_per_thread)),
+        "kernel": "draw kernel (CB_KERNEL_FULL_ITERATE: early-out off, %.1f iterations/sample executed)"
+                  % (fiters / (job.threads * job.samples)),
         "achieved": round(ftf, 3),
         "peak": PEAK_FP64_VECTOR_TFLOPS,
         "unit": "TFLOP/s",
         "frac": round(ftf / PEAK_FP64_VECTOR_TFLOPS, 4),
-        # ~97 % of this variant's iterations are LONG-stage steps (4.1 instructions), the rest tested steps (7)
-        "issue_frac": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
-                            / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
+        # a MODEL, not a counter: ~97 % of this variant's iterations are LONG-stage steps (4.1 instructions), the
+        # rest tested steps (7); the counter-based utilisation of the product kernel is roofline.valu_busy
+        "issue_frac_model": round(ftf / FLOPS_PER_ITERATION * (0.97 * LONG_SLOTS_PER_ITERATION + 0.03 * ISSUE_SLOTS_PER_ITERATION)
+                                  / (PEAK_FP64_VECTOR_TFLOPS / 2), 4),
         "avg_launch_ms": round(fms, 4),
         "launch_ms": [round(x, 3) for x in f_each],   # the launches of samples, then the drain launch
-        "msamples_per_s_kernel_only": round(threads * samples_per_thread / (fms * 1e-3) / 1e6, 1),
+        "msamples_per_s_kernel_only": round(job.threads * job.samples / (fms * 1e-3) / 1e6, 1),
     }
     return result
+
+
+class Job:
+    """Device buffers of one workload on one GPU and the two calls of a step (draw launch, scatter), driven like
+    cb_renderer (capi.hip): two workspaces, the scatter of launch k on its own stream behind draw k."""
+
+    def __init__(self, cb, torch, dev, w, h, windows, box, first, threads, samples_per_thread, direct_atomics=False,
+                 single_stream=False):
+        self.cb, self.torch = cb, torch
+        self.dims = cb.FractalDimensions.make(w, h, *box) if box else cb.FractalDimensions.make(w, h)
+        self.windows = windows if len(windows) > 1 else None        # fused channels: [(max, min), ...]
+        self.it = cb.IterationControl(*windows[0])
+        self.planes = len(windows)
+        self.threads, self.samples = threads, samples_per_thread
+        self.hist = torch.zeros(self.planes * w * h, dtype=torch.int64, device=dev)     # u64 counters
+        self.states = torch.empty(cb.rng_state_bytes(threads), dtype=torch.uint8, device=dev)
+        self.counters = torch.zeros(17, dtype=torch.int64, device=dev)
+        self.draw_stream_t = torch.cuda.current_stream()
+        self.stream = self.draw_stream_t.cuda_stream
+        cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, first, threads, self.states.data_ptr(), self.stream)
+        # scratch for the deferred tile-binned scatter (pixel stream + its sorted copy), ~12 GiB of 288 at C3
+        self.ws_bytes = 0 if direct_atomics else cb.scatter_workspace_bytes(self.dims, threads, samples_per_thread,
+                                                                            self.planes)
+        self.workspaces = [torch.empty(max(self.ws_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.flush_stream_t = self.draw_stream_t if single_stream else torch.cuda.Stream(device=dev)
+        self.flush_stream = self.flush_stream_t.cuda_stream
+        self.draw_done = [torch.cuda.Event() for _ in range(2)]
+        self.flush_done = [torch.cuda.Event() for _ in range(2)]
+        self.flush_pending = [False, False]
+        self.turn = 0
+        # orbits still in flight at the end of a launch are carried to the next one instead of being drained at a
+        # fraction of the lanes; a launch without samples (inside the timed region) completes them
+        self.carry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
+
+    def draw(self, samples, k, variant=None, stream=None, carry=None):
+        cb = self.cb
+        variant = cb.CB_KERNEL_DEFAULT if variant is None else variant
+        ws = self.workspaces[k].data_ptr() if self.ws_bytes else 0
+        carry = self.carry if carry is None else carry
+        if self.windows:
+            cb.draw_buddhabrot_channels(self.dims, self.hist.data_ptr(), self.windows, self.states.data_ptr(),
+                                        self.threads, samples, self.counters.data_ptr(), variant,
+                                        stream or self.stream, ws, self.ws_bytes, carry.data_ptr())
+        else:
+            cb.draw_buddhabrot(self.dims, self.hist.data_ptr(), self.it, self.states.data_ptr(), self.threads, samples,
+                               self.counters.data_ptr(), variant, stream or self.stream, ws, self.ws_bytes,
+                               carry.data_ptr())
+
+    def flush(self, k, stream=None):
+        cb = self.cb
+        if not self.ws_bytes:
+            return
+        if self.windows:
+            cb.flush_scatter_channels(self.dims, self.hist.data_ptr(), self.planes, self.threads,
+                                      self.workspaces[k].data_ptr(), self.ws_bytes, stream or self.flush_stream)
+        else:
+            cb.flush_scatter(self.dims, self.hist.data_ptr(), self.threads, self.workspaces[k].data_ptr(), self.ws_bytes,
+                             stream or self.flush_stream)
+
+    def step(self, samples=None, ev_draw=None, ev_flush=None):
+        """One launch of the dominant kernel (sample -> iterate -> replay, cudabrot.cu:379-414) on the draw
+        stream and its scatter on the flush stream."""
+        samples = self.samples if samples is None else samples
+        k = self.turn
+        if self.flush_pending[k]:
+            self.draw_stream_t.wait_event(self.flush_done[k])     # workspace k is free once its last scatter is done
+            self.flush_pending[k] = False
+        if ev_draw:
+            ev_draw[0].record(self.draw_stream_t)
+        self.draw(samples, k)
+        if ev_draw:
+            ev_draw[1].record(self.draw_stream_t)
+        if self.ws_bytes:
+            self.draw_done[k].record(self.draw_stream_t)
+            self.flush_stream_t.wait_event(self.draw_done[k])
+            if ev_flush:
+                ev_flush[0].record(self.flush_stream_t)
+            self.flush(k)     # partition the deferred pixel stream by tile and add it to the histogram
+            if ev_flush:
+                ev_flush[1].record(self.flush_stream_t)
+            self.flush_done[k].record(self.flush_stream_t)
+            self.flush_pending[k] = True
+            self.turn = k ^ 1
+
+    def counter_values(self, np):
+        return dict(zip(self.cb.Counters().as_dict().keys(),
+                        (int(v) for v in self.counters.cpu().numpy().view(np.uint64))))
+
+    def sequential_leg(self, np, launches=4, timed_from=2):
+        """The draw launch and the scatter kernels ALONE (one stream, a sync between them): in the pipeline they share
+        the GPU with each other, so their event-to-event times there include waiting for CUs.  Returns the lists of
+        draw ms, scatter ms and increments of the timed launches; ends with a drain so nothing stays in flight."""
+        torch = self.torch
+        draw_ms, flush_ms, incr = [], [], []
+        for n in range(launches):
+            before = int(self.counters.cpu().numpy().view(np.uint64)[7])
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
+            self.draw(self.samples, 0)
+            d1.record()
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            self.flush(0, stream=self.stream)
+            c1.record()
+            torch.cuda.synchronize()
+            if n >= timed_from:
+                draw_ms.append(d0.elapsed_time(d1))
+                flush_ms.append(c0.elapsed_time(c1))
+                incr.append(int(self.counters.cpu().numpy().view(np.uint64)[7]) - before)
+        self.draw(0, 0)
+        self.flush(0, stream=self.stream)
+        torch.cuda.synchronize()
+        return draw_ms, flush_ms, incr
+
+
+def other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread, steps=6):
+    """A short leg of another BASELINE.json config, BEFORE the clock of the headline workload and not part of
+    `value`: Msamples/s of `steps` pipelined launches + the drain launch (wall clock between device syncs, one warm-up
+    step first), and the draw launch / the scatter kernels alone.  The histogram is checked against the in-kernel
+    increment counter; parity with the reference is what tests/ do at these sizes (tests/test_gpu_full_size.py)."""
+    w, h, max_iter, min_iter = CONFIGS[name]
+    windows = C5_WINDOWS if name == "C5" else [(max_iter, min_iter)]
+    job = Job(cb, torch, dev, w, h, windows, C5_BOX if name == "C5" else None, 0, threads, samples_per_thread)
+    try:
+        draw_ms, flush_ms, _ = job.sequential_leg(np, launches=3, timed_from=1)
+        job.step()
+        job.step(0)
+        torch.cuda.synchronize()
+        job.counters.zero_()
+        job.hist.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step()
+        job.step(0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cnt = job.counter_values(np)
+        assert cnt["status"] == 0 and cnt["samples"] == threads * samples_per_thread * steps, cnt
+        assert int(job.hist.sum().item()) == cnt["increments"], "histogram and increment counter differ"
+        out = {
+            "workload": ("%dx%d on [%g,%g]x[%g,%g], fused windows %s" % ((w, h) + C5_BOX + (C5_WINDOWS,)))
+                        if name == "C5" else "%dx%d canvas on [-2,2]^2, max_iter=%d, min_iter=%d" % (w, h, max_iter, min_iter),
+            "msamples_per_s": round(cnt["samples"] / dt / 1e6, 1),
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps,
+            "draw_alone_ms": round(sum(draw_ms) / len(draw_ms), 3),
+            "scatter_alone_ms": round(sum(flush_ms) / len(flush_ms), 3),
+            "workspace_gib": round(job.ws_bytes / 2.0 ** 30, 2),
+            "increments_per_sample": round(cnt["increments"] / cnt["samples"], 4),
+        }
+    finally:
+        del job
+        torch.cuda.empty_cache()
+    return out
 
 
 def baseline_metric():
@@ -192,13 +398,16 @@ def main():
     ap.add_argument("--no-reference", action="store_true")
     ap.add_argument("--no-full-iterate", action="store_true",
                     help="skip the extra launches that measure the iterate loop with the early-out off")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short before-the-clock legs of C4, C2 and C5 (`other_configs`)")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
     ap.add_argument("--single-stream", action="store_true",
                     help="A/B: issue the scatter of launch k behind draw k on the same stream instead of on a second "
                          "stream beside draw k+1 (measured: 2 % slower)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C3",
-                    help="workload: C3 (default, the config BASELINE.json's metric is quoted on), C4 (20000x20000), C2")
+                    help="workload: C3 (default, the config BASELINE.json's metric is quoted on), C4 (20000x20000), C2, "
+                         "C5 (the colour recipe's three windows fused, 20000x15000)")
     args = ap.parse_args()
     global W, H, MAX_ITER, MIN_ITER
     W, H, MAX_ITER, MIN_ITER = CONFIGS[args.config]
@@ -230,59 +439,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    dims = cb.FractalDimensions.make(W, H)
-    it = cb.IterationControl(MAX_ITER, MIN_ITER)
     first, threads = shard_subsequences(rank, world, THREADS)
-    hist = torch.zeros(W * H, dtype=torch.int64, device=dev)              # u64 counters
-    states = torch.empty(cb.rng_state_bytes(threads), dtype=torch.uint8, device=dev)
-    counters = torch.zeros(17, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, first, threads, states.data_ptr(), stream)
     samples_per_thread = SAMPLES_PER_PASS * PASSES_PER_STEP
-    # scratch for the deferred tile-binned scatter (pixel stream + its sorted copy), ~12 GiB of 288 each.
-    # Two of them and two streams, exactly as cb_renderer (capi.hip) drives the path: the scatter of
-    # launch k is issued on its own stream behind draw k, and draw k+1 starts at once on the other
-    # workspace, so that the scatter's first kernels fill the CUs the draw kernel's tail leaves idle.
-    ws_bytes = 0 if args.direct_atomics else cb.scatter_workspace_bytes(dims, threads, samples_per_thread)
-    workspaces = [torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev) for _ in range(2)]
-    draw_stream_t = torch.cuda.current_stream()
-    flush_stream_t = draw_stream_t if args.single_stream else torch.cuda.Stream(device=dev)
-    flush_stream = flush_stream_t.cuda_stream
-    draw_done = [torch.cuda.Event() for _ in range(2)]
-    flush_done = [torch.cuda.Event() for _ in range(2)]
-    flush_pending = [False, False]
-    turn = [0]
-
-    # orbits still in flight at the end of a launch are carried to the next one instead of being
-    # drained at a fraction of the lanes; the drain launch below, INSIDE the timed region, completes them
-    carry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
-
-    def step(samples=samples_per_thread, ev_draw=None, ev_flush=None):
-        """One launch of the dominant kernel (sample -> iterate -> replay, cudabrot.cu:379-414) on the draw
-        stream and its scatter on the flush stream."""
-        k = turn[0]
-        if flush_pending[k]:
-            draw_stream_t.wait_event(flush_done[k])     # workspace k is free once its last scatter is done
-            flush_pending[k] = False
-        if ev_draw:
-            ev_draw[0].record(draw_stream_t)
-        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples,
-                           counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
-                           workspaces[k].data_ptr() if ws_bytes else 0, ws_bytes, carry.data_ptr())
-        if ev_draw:
-            ev_draw[1].record(draw_stream_t)
-        if ws_bytes:
-            draw_done[k].record(draw_stream_t)
-            flush_stream_t.wait_event(draw_done[k])
-            if ev_flush:
-                ev_flush[0].record(flush_stream_t)
-            # partition the deferred pixel stream by tile and add it to the histogram
-            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[k].data_ptr(), ws_bytes, flush_stream)
-            if ev_flush:
-                ev_flush[1].record(flush_stream_t)
-            flush_done[k].record(flush_stream_t)
-            flush_pending[k] = True
-            turn[0] = k ^ 1
 
     def fence():
         torch.cuda.synchronize()
@@ -294,42 +452,35 @@ def main():
     # They used to follow the timed region; run first they also bring the device to its working clocks: the
     # first launches on an idle GPU take 10 %, 4 %, 2 % ... longer, and the driver's run has five warm-up steps.
     #
-    # (1) The draw launch and the scatter kernels ALONE, for alone_ms and roofline_scatter: in the pipeline of
-    # the timed region they share the GPU with each other, so their event-to-event times there include waiting
-    # for CUs.  Four sequential launches on one stream, the last two timed.
+    # (0) the other BASELINE.json configs, each with buffers of its own, freed before the headline workload's
+    other_configs = None
+    if world == 1 and not args.no_other_configs and not args.direct_atomics:
+        other_configs = {}
+        for name in ("C4", "C2", "C5", "C3"):
+            if name == args.config:
+                continue
+            try:
+                other_configs[name] = other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread)
+            except Exception as e:   # a leg that fails says so in the line; it never takes the headline down
+                other_configs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+
+    windows = C5_WINDOWS if args.config == "C5" else [(MAX_ITER, MIN_ITER)]
+    job = Job(cb, torch, dev, W, H, windows, C5_BOX if args.config == "C5" else None, first, threads, samples_per_thread,
+              direct_atomics=args.direct_atomics, single_stream=args.single_stream)
+    ws_bytes, hist, counters = job.ws_bytes, job.hist, job.counters
+    # (1) The draw launch and the scatter kernels ALONE, for alone_ms and roofline_scatter.  Four sequential
+    # launches on one stream, the last two timed.
     seq_flush_ms, seq_incr, seq_draw_ms = [], [], []
     if ws_bytes:
-        for n in range(4):
-            before = int(counters.cpu().numpy().view(np.uint64)[7])
-            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d0.record()
-            cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples_per_thread,
-                               counters.data_ptr(), cb.CB_KERNEL_DEFAULT, stream,
-                               workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
-            d1.record()
-            torch.cuda.synchronize()
-            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            c0.record()
-            cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
-            c1.record()
-            torch.cuda.synchronize()
-            if n >= 2:
-                seq_draw_ms.append(d0.elapsed_time(d1))
-                seq_flush_ms.append(c0.elapsed_time(c1))
-                seq_incr.append(int(counters.cpu().numpy().view(np.uint64)[7]) - before)
-        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, 0, counters.data_ptr(),
-                           cb.CB_KERNEL_DEFAULT, stream, workspaces[0].data_ptr(), ws_bytes, carry.data_ptr())
-        cb.flush_scatter(dims, hist.data_ptr(), threads, workspaces[0].data_ptr(), ws_bytes, stream)
-        torch.cuda.synchronize()
+        seq_draw_ms, seq_flush_ms, seq_incr = job.sequential_leg(np)
     # (2) the iterate loop against its roofline (one GPU only): see full_iterate_leg
     full_iterate = None
     if world == 1 and not args.no_full_iterate:
-        full_iterate = full_iterate_leg(cb, torch, np, dims, it, hist, states, counters, threads, samples_per_thread, stream,
-                                        workspaces[0], ws_bytes, dev)
+        full_iterate = full_iterate_leg(job, torch, np, dev)
 
     for _ in range(args.warmup):
-        step()
-    step(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
+        job.step()
+    job.step(0)      # complete the warm-up's orbits: the timed region starts with nothing in flight
     fence()
     counters.zero_()
     hist.zero_()     # from here on every increment the histogram holds is also in `counters`
@@ -339,12 +490,12 @@ def main():
     fence()
     t0 = time.perf_counter()
     for a, b, c, d in ev:
-        step(ev_draw=(a, b), ev_flush=(c, d))
-    dev_ev[0].record(draw_stream_t)
-    step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
+        job.step(ev_draw=(a, b), ev_flush=(c, d))
+    dev_ev[0].record(job.draw_stream_t)
+    job.step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
-    dev_ev[1].record(draw_stream_t)
+    dev_ev[1].record(job.draw_stream_t)
     torch.cuda.synchronize()
     drain_ms = dev_ev[0].elapsed_time(dev_ev[1])
     kernel_ms = [a.elapsed_time(b) for a, b, _, _ in ev]   # HIP events on the draw stream: the draw kernel
@@ -386,7 +537,8 @@ def main():
         # EXECUTED iterations: the reference's count minus what the exact-periodicity check retired early
         iters_per_launch = (loc["iterate_steps"] - loc["skipped_steps"] + loc["replay_steps"]) / args.steps
         incr_per_launch = loc["increments"] / args.steps
-        traffic = recorded_traffic(threads * samples_per_thread)
+        traffic = recorded_traffic(threads * samples_per_thread) if args.config == "C3" else None
+        busy = recorded_valu_busy(threads * samples_per_thread) if args.config == "C3" else None
         tflops = iters_per_launch * FLOPS_PER_ITERATION / (avg_ms * 1e-3) / 1e12
         if ws_bytes:   # the scatter kernels alone (sequential leg before the clock)
             scatter_ms = sum(seq_flush_ms) / len(seq_flush_ms)
@@ -394,6 +546,10 @@ def main():
         else:          # direct atomics happen inside the draw kernel
             scatter_ms, scatter_incr = avg_ms, incr_per_launch
         scatter_gbps = scatter_incr * BYTES_PER_INCREMENT / (scatter_ms * 1e-3) / 1e9
+        if args.config == "C5":
+            workload = "C5: %dx%d canvas on [%g,%g]x[%g,%g], fused windows (max, min) %s" % ((W, H) + C5_BOX + (C5_WINDOWS,))
+        else:
+            workload = "%s: %dx%d canvas on [-2,2]^2, max_iter=%d, min_iter=%d" % (args.config, W, H, MAX_ITER, MIN_ITER)
         line = {
             "metric": baseline_metric(),
             "value": round(samples / elapsed / 1e6, 3),
@@ -409,7 +565,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic (seeded XORWOW sample stream, rocRAND-compatible, seed 1337)",
             "config": {
-                "workload": "%s: %dx%d canvas on [-2,2]^2, max_iter=%d, min_iter=%d" % (args.config, W, H, MAX_ITER, MIN_ITER),
+                "workload": workload,
                 "threads_per_gpu": threads,
                 "samples_per_step_per_gpu": threads * samples_per_thread,
                 "passes_per_step": PASSES_PER_STEP,
@@ -429,7 +585,7 @@ def main():
             "histogram_reduce_ms": round(reduce_ms, 3),
             "roofline": {
                 "bound": "valu_fp64",
-                "kernel": "draw_wave_kernel",
+                "kernel": "draw kernel (draw_wave.hip / draw_wide.hip)",
                 "achieved": round(tflops, 3),
                 "peak": PEAK_FP64_VECTOR_TFLOPS,
                 "unit": "TFLOP/s",
@@ -447,16 +603,17 @@ def main():
                         "~13 % of the reference's iterations are executed).  The kernel spends fewer fp64 instructions than "
                         "that on most of them: a tested step is 6 fp64 instructions + 1 compare (doubled-coordinate form), "
                         "and the LONG stage -- escape is absorbing, so it tests once per chunk of 60 steps and decides the rare "
-                        "sample with |c| next to 2 exactly -- 4.1 per step; it also draws, tests and replays, so `frac` is neither a "
-                        "ceiling-bounded utilisation nor comparable with round 1's (which issued 7 per step everywhere).  "
-                        "avg_launch_ms is measured in the pipelined timed region, where the scatter kernels of the previous "
-                        "launch share the GPU (alone_ms / frac_alone: the same launch with nothing beside it, before the "
-                        "clock); peak is the 2.4 GHz spec figure, the shader clock under this load is ~2.08 GHz (DESIGN.md 4.4)",
+                        "sample with |c| next to 2 exactly -- 4.1 per step; it also draws, tests and replays, so `frac` is NOT a "
+                        "ceiling-bounded utilisation.  The bounded one is `valu_busy`: SQ_INSTS_VALU of the committed rocprofv3 "
+                        "counter pass (valu_busy_source) x 4 cycles over the SIMD-cycles of the same profiled dispatch, at the "
+                        "2.4 GHz spec clock and at the clock the same counters give.  avg_launch_ms is measured in the pipelined "
+                        "timed region, where the scatter kernels of the previous launch share the GPU (alone_ms / frac_alone: "
+                        "the same launch with nothing beside it, before the clock)",
             },
             "roofline_scatter": {
                 "bound": "hbm",
                 "kernel": "bin_region_sort + bin_gather_accumulate (+ region / slice tables)" if ws_bytes
-                          else "atomics inside draw_wave_kernel",
+                          else "atomics inside the draw kernel",
                 "avg_launch_ms": round(scatter_ms, 4),
                 "achieved": round(scatter_gbps, 2),
                 "peak": PEAK_HBM_GBPS,
@@ -467,16 +624,24 @@ def main():
                 "pipelined_ms": round(avg_flush_ms, 4),
                 "traffic": traffic["scatter"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
+                # the same rate against the bytes the counters saw (fabric side) instead of the algorithmic 16 B
+                "achieved_counter_gbps": round(traffic["scatter"] / (scatter_ms * 1e-3) / 1e9, 2) if traffic else None,
+                "frac_counter": round(traffic["scatter"] / (scatter_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5) if traffic else None,
                 "note": "16 B per histogram increment (u64 read+write), increments counted in-kernel, over the time "
                         "of the scatter kernels run alone (two launches before the clock); pipelined_ms is their "
                         "event-to-event time inside the timed region, where they share the GPU with the next "
                         "draw launch; random u64 atomics measured at ~24 Gop/s (= 380 GB/s on this scale).  `traffic` "
-                        "(fabric bytes, PMC) is what HBM sees: ~15 GB per launch, 4.4 TB/s over the whole scatter, 4.8-5.2 TB/s "
-                        "in the region sort -- 0.8 of the 6.29 TB/s a float4 copy reaches (DESIGN.md 7)",
+                        "(fabric bytes per launch, PMC passes of traffic_source) is what HBM sees; achieved_counter_gbps / "
+                        "frac_counter price those bytes over the same time: the LDS tiles absorb repeats, so they are fewer "
+                        "than the algorithmic ones",
             },
         }
+        if busy:
+            line["roofline"].update(busy)
         if full_iterate is not None:
             line["roofline_full_iterate"] = full_iterate
+        if other_configs is not None:
+            line["other_configs"] = other_configs
         if world == 1 and not args.no_reference:
             ref = reference_gpu()
             if ref:

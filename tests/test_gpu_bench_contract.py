@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 def test_bench_prints_one_json_line_with_the_contract_keys(repo_root):
     r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--steps", "2", "--warmup", "1",
-                        "--no-reference", "--no-full-iterate"],
+                        "--no-reference", "--no-full-iterate", "--no-other-configs"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=repo_root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [x for x in r.stdout.splitlines() if x.strip()]
@@ -34,3 +34,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys(repo_root):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     cpu = b["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+
+
+def test_bench_line_carries_the_other_configs(repo_root):
+    """`other_configs`: short before-the-clock legs of BASELINE.json's C4, C2 and C5 (fused recipe windows) in the
+    one JSON line, each checked inside bench.py against its own increment counter."""
+    r = subprocess.run([sys.executable, os.path.join(repo_root, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--no-reference", "--no-full-iterate", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=repo_root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([x for x in r.stdout.splitlines() if x.strip()][-1])
+    oc = b["other_configs"]
+    assert set(oc) == {"C4", "C2", "C5"}
+    for name, leg in oc.items():
+        assert "error" not in leg, (name, leg)
+        assert leg["msamples_per_s"] > 0 and leg["draw_alone_ms"] > 0 and leg["scatter_alone_ms"] > 0
+        assert leg["workspace_gib"] > 0
+    assert b["config"]["workload"].startswith("C3")

@@ -7,7 +7,7 @@ for L in "$@"; do
   (cd cudabrot_amd/csrc && make -j8 -s > ../../gpurun_out/chunk_build_$L.log 2>&1) || { echo "build failed for $L"; tail -5 gpurun_out/chunk_build_$L.log; exit 1; }
   for rep in 1 2; do
     log=gpurun_out/chunk_${L}_$rep.json
-    timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference --no-full-iterate > "$log" 2> "$log.err"
+    timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs > "$log" 2> "$log.err"
     rc=$?
     if [ $rc -ne 0 ]; then echo "bench failed ($rc) at chunk $L"; tail -3 "$log.err"; exit 1; fi
     python3 - "$L" "$log" <<'PY'

@@ -4,7 +4,7 @@ set -u
 mkdir -p gpurun_out
 for v in "$@"; do
   log=gpurun_out/flush_ab_$(echo "$v" | tr '= ' '__').json
-  timeout -k 10 200 env $v python3 bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-reference --no-full-iterate > "$log" 2> "$log.err"
+  timeout -k 10 200 env $v python3 bench.py --steps ${STEPS:-10} --warmup 2 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs > "$log" 2> "$log.err"
   rc=$?
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT at $v: stopping"; exit 1; fi
   python3 - "$v" "$log" <<'PY'

@@ -16,7 +16,7 @@ run() {  # run <seconds> <logfile> <cmd...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: stopping session"; exit 1; fi
   return 0
 }
-BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate"
+BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
 run 400 "$OUT/bench_full.json" python3 bench.py
 run 300 "$OUT/stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS
 run 300 "$OUT/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS

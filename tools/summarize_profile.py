@@ -19,7 +19,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
-KERNELS = ("draw_wave_kernel", "bin_region_heads_kernel", "bin_fill_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
+KERNELS = ("draw_wave_kernel", "draw_wide_kernel", "bin_region_heads_kernel", "bin_fill_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
            "bin_gather_accumulate_kernel", "group_count_kernel", "group_scan_rows_kernel", "group_scan_keys_kernel",
            "group_scatter_kernel")
 
@@ -56,11 +56,23 @@ def traffic(kernels):
 
 # per-dispatch durations of the draw kernel from the kernel trace (the timed steps, the warm-up and the
 # drain launches of one bench run)
-durations = []
-for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
-    for r in csv.DictReader(open(f)):
-        if "draw_wave_kernel" in r["Kernel_Name"]:
-            durations.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4))
+def draw_durations(pass_dir):
+    out = []
+    for f in glob.glob(os.path.join(src, pass_dir, "*", "*_kernel_trace.csv")):
+        for r in csv.DictReader(open(f)):
+            if "draw_wave_kernel" in r["Kernel_Name"] or "draw_wide_kernel" in r["Kernel_Name"]:
+                out.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6, 4))
+    return out
+
+
+durations = draw_durations("trace")
+# ... and of every counter pass (a profiled pass runs a few per cent slower than an unprofiled one: a counter is
+# only ever divided by the duration of the dispatches it was counted in); median = a steady launch of samples
+durations_by_pass = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    v = draw_durations(os.path.basename(d))
+    if v:
+        durations_by_pass[os.path.basename(d)] = {"median": sorted(v)[len(v) // 2], "all": v}
 
 bench = None
 bf = os.path.join(src, "bench_full.json")
@@ -74,8 +86,8 @@ out = {
     "source": src,
     "pmc": pmc,
     "traffic_bytes_per_launch": {
-        "draw_wave_kernel": traffic(["draw_wave_kernel"]),
-        "scatter_kernels": traffic([k for k in KERNELS if k != "draw_wave_kernel"]),
+        "draw_wave_kernel": traffic(["draw_wave_kernel", "draw_wide_kernel"]),
+        "scatter_kernels": traffic([k for k in KERNELS if not k.startswith("draw_")]),
         "region_sort": traffic(["bin_region_sort_kernel"]),
         "gather_accumulate": traffic(["bin_gather_accumulate_kernel"]),
         "note": "per launch of 64 fused passes; fabric-side (TCC_EA) bytes, Infinity-Cache hits included; FETCH_SIZE is "
@@ -84,6 +96,7 @@ out = {
                 "bound for bin_gather_accumulate_kernel, whose 16-byte loads of short runs may be served in 64-byte requests",
     },
     "draw_wave_kernel_dispatch_ms": durations,
+    "draw_dispatch_ms_by_pass": durations_by_pass,
     "bench_line": bench,
 }
 json.dump(out, open(dst + "_summary.json", "w"), indent=1)
