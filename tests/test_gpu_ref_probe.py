@@ -20,11 +20,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def probe(cb, oracle):
-    path = os.path.join(oracle.REF_DIR, "libref_probe.so")
+def load_probe(cb, oracle, name):
+    path = os.path.join(oracle.REF_DIR, name)
     if not os.path.exists(path):
-        pytest.skip("oracle/_ref/libref_probe.so not built (make -C oracle ref, needs /root/reference)")
+        pytest.skip("oracle/_ref/%s not built (make -C oracle ref, needs /root/reference)" % name)
     p = C.CDLL(path)  # after cudabrot_amd: one HIP runtime per process (cudabrot_amd/capi.py)
     p.ref_probe_points.restype = C.c_int
     p.ref_probe_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -32,6 +31,28 @@ def probe(cb, oracle):
     p.ref_probe_record.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]
     return p
+
+
+@pytest.fixture(scope="module")
+def probe(cb, oracle):
+    return load_probe(cb, oracle, "libref_probe.so")
+
+
+@pytest.fixture(scope="module")
+def probe_ship(cb, oracle):
+    """The same device functions compiled with -DRENDER_BURNING_SHIP=1 (cudabrot.cu:15-17): the on-device pin of
+    the variant, with no stand-in of any kind."""
+    return load_probe(cb, oracle, "libref_probe_ship.so")
+
+
+@pytest.fixture
+def ship_oracle(oracle):
+    """The oracle's step with the reference's fabs lines (cudabrot.cu:327-330,353-356) switched on."""
+    oracle.lib.orc_set_burning_ship(1)
+    try:
+        yield oracle
+    finally:
+        oracle.lib.orc_set_burning_ship(0)
 
 
 def stream_points(oracle, n_threads, per_thread):
@@ -123,4 +144,85 @@ def test_visited_pixels_of_the_reference_on_gfx950(probe, oracle, cb, canvas):
         got = r.read_histogram()
         cnt = r.read_counters().as_dict()
     assert cnt["status"] == 0 and cnt["recorded"] == len(acc)
+    assert np.array_equal(got, dev.astype(np.uint64))
+
+
+def test_window_edges_of_the_reference_on_gfx950(probe, oracle, cb):
+    """The accept filter of cudabrot.cu:407-408 with `-c 0` (nothing is too fast) and with the recipe's deepest window
+    (60000, 45000): the reference's escape indices on the device decide which samples record, its IterateAndRecord
+    records them, and the product's histogram for the same samples must equal that."""
+    w, h, box = 512, 512, (-2.0, 2.0, -2.0, 2.0)
+    for max_iter, min_iter, threads, per_thread in ((20000, 0, 512, 50), (60000, 45000, 4096, 50)):
+        pts = stream_points(oracle, threads, per_thread)
+        k, s = device_points(probe, pts, max_iter)
+        keep = (s == 0) & (k >= min_iter) & (k < max_iter)
+        acc = pts[keep]
+        dev = np.zeros((h, w), dtype=np.uint32)
+        if len(acc):
+            re = np.ascontiguousarray(acc[:, 0])
+            im = np.ascontiguousarray(acc[:, 1])
+            rc = probe.ref_probe_record(w, h, box[0], box[1], box[2], box[3], re.ctypes.data, im.ctypes.data, len(acc),
+                                        dev.ctypes.data)
+            assert rc == 0, "HIP error %d in the probe" % rc
+        if min_iter == 0:
+            assert len(acc) > 5000          # every escaping sample outside the shortcut regions records
+        dims = cb.FractalDimensions.make(w, h, *box)
+        with cb.Renderer(dims, cb.IterationControl(max_iter, min_iter), n_threads=threads) as r:
+            r.render_passes(1)
+            got = r.read_histogram()
+            cnt = r.read_counters().as_dict()
+        assert cnt["status"] == 0 and cnt["recorded"] == len(acc), (max_iter, min_iter, cnt["recorded"], len(acc))
+        assert cnt["too_fast"] == int(((s == 0) & (k < min_iter)).sum())
+        assert cnt["never_escaped"] == int(((s == 0) & (k >= max_iter)).sum())
+        assert np.array_equal(got, dev.astype(np.uint64))
+
+
+def test_burning_ship_escape_index_of_the_reference_on_gfx950(probe_ship, ship_oracle):
+    """IterateMandelbrot of the RENDER_BURNING_SHIP build on the device == the oracle's ship step."""
+    oracle = ship_oracle
+    max_iter = 20000
+    pts = np.concatenate([stream_points(oracle, 256, 50), boundary_points()])
+    k, _ = device_points(probe_ship, pts, max_iter)
+    deep = 0
+    for j, (re, im) in enumerate(pts):
+        if k[j] == max_iter:
+            deep += 1
+            if deep > 1500:
+                continue
+        assert oracle.lib.orc_iterate_mandelbrot(re, im, max_iter) == k[j], ("k", re.hex(), im.hex(), int(k[j]))
+    assert int((k < max_iter).sum()) > 5000
+
+
+@pytest.mark.parametrize("canvas", [
+    (4096, 4096, (-2.0, 2.0, -2.0, 2.0)),
+    (333, 77, (-1.9, 1.3, -1.8, 0.4)),
+], ids=["dyadic_4096", "odd_crop"])
+def test_burning_ship_visited_pixels_of_the_reference_on_gfx950(probe_ship, ship_oracle, cb, canvas):
+    """IterateAndRecord of the RENDER_BURNING_SHIP build on the device == the oracle == the product's ship build
+    (no cardioid / bulb shortcut in this variant, cudabrot.cu:397-399)."""
+    oracle = ship_oracle
+    w, h, box = canvas
+    max_iter, min_iter = 2000, 20
+    threads, per_thread = 1024, 50
+    pts = stream_points(oracle, threads, per_thread)
+    k, _ = device_points(probe_ship, pts, max_iter)
+    keep = (k >= min_iter) & (k < max_iter)                     # cudabrot.cu:407-408; :398 is compiled out
+    acc = pts[keep]
+    assert len(acc) > 300
+    re = np.ascontiguousarray(acc[:, 0])
+    im = np.ascontiguousarray(acc[:, 1])
+    dev = np.empty((h, w), dtype=np.uint32)
+    rc = probe_ship.ref_probe_record(w, h, box[0], box[1], box[2], box[3], re.ctypes.data, im.ctypes.data, len(acc),
+                                     dev.ctypes.data)
+    assert rc == 0, "HIP error %d in the probe" % rc
+    mine, steps, incr = oracle.record_points(w, h, box, re, im)
+    assert steps == int((k[keep] + 1).sum())
+    assert incr == int(dev.sum())
+    assert np.array_equal(mine, dev.astype(np.uint64))
+    dims = cb.FractalDimensions.make(w, h, *box)
+    with cb.Renderer(dims, cb.IterationControl(max_iter, min_iter), n_threads=threads) as r:
+        r.render_passes(1, cb.CB_KERNEL_DEFAULT | cb.CB_KERNEL_FLAG_BURNING_SHIP)
+        got = r.read_histogram()
+        cnt = r.read_counters().as_dict()
+    assert cnt["status"] == 0 and cnt["recorded"] == len(acc) and cnt["rejected"] == 0
     assert np.array_equal(got, dev.astype(np.uint64))
