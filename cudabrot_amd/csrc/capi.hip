@@ -106,9 +106,9 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
     a.fast_mid = (a.min_iter >= a.head_steps + a.mid_steps && long_steps > 0) ? 1 : 0;
     a.long_start = a.head_steps + a.mid_steps;
     a.tail_start = a.long_start + (int) (a.long_steps - a.tail_steps);
-    a.sparse_long = (long_steps > 0 && a.min_iter <= a.long_start && getenv("CUDABROT_AMD_DENSE_TESTS") == nullptr) ? 1 : 0;
+    a.sparse_long = (long_steps > 0 && a.min_iter <= a.long_start && cb_debug_knob("CUDABROT_AMD_DENSE_TESTS") == nullptr) ? 1 : 0;
     a.sparse_threshold = 16.0 - 0x1p-10;
-    if (const char *e = getenv("CUDABROT_AMD_SPARSE_THRESHOLD")) {  // test knob: only ever lower
+    if (const char *e = cb_debug_knob("CUDABROT_AMD_SPARSE_THRESHOLD")) {  // test knob: only ever lower
       const double v = atof(e);
       if (v > 0.0 && v < a.sparse_threshold) a.sparse_threshold = v;
     }
@@ -377,7 +377,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
       a.check_periodic = 0;
       return (int) wave(a, false, s);
     case CB_KERNEL_TIMED:
-      if (getenv("CUDABROT_AMD_TIMED_FULL")) a.check_periodic = 0;  // diagnostic: stage clocks of the full-iterate form
+      if (cb_debug_knob("CUDABROT_AMD_TIMED_FULL")) a.check_periodic = 0;  // diagnostic: stage clocks of the full-iterate form
       return (int) wave(a, true, s);
     case CB_KERNEL_SIMPLE:
       return (int) cb::launch_draw_simple(a, s);
@@ -506,7 +506,7 @@ namespace {
 // 50 samples per thread per reference pass (cudabrot.cu:34,390), at most kRendererPassesPerLaunch passes per launch.
 uint32_t max_passes_per_launch() {
   static const uint32_t v = [] {
-    const char *e = getenv("CUDABROT_AMD_PASSES_PER_LAUNCH");  // experiment knob
+    const char *e = cb_debug_knob("CUDABROT_AMD_PASSES_PER_LAUNCH");  // experiment knob
     const long n = e ? atol(e) : 0;
     return (n >= 1 && n <= 4096) ? (uint32_t) n : kRendererPassesPerLaunch;
   }();
@@ -516,7 +516,7 @@ uint32_t max_passes_per_launch() {
 // What a renderer allocates on first use, because it depends on the kernel variant: the two scatter
 // workspaces (tens of GB on a large canvas -- hipMalloc of that size can take seconds).
 void prepare_for_variant(cb_renderer *r, int kernel_variant) {
-  if ((kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) == CB_KERNEL_TIMED && getenv("CUDABROT_AMD_WAVE_DUMP") &&
+  if ((kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) == CB_KERNEL_TIMED && cb_debug_knob("CUDABROT_AMD_WAVE_DUMP") &&
       !g_wave_dump) {
     const size_t bytes = (size_t) cb::draw_wave_count(r->n_threads) * 8 * sizeof(unsigned long long);
     if (hipMalloc(&g_wave_dump, bytes) != hipSuccess || hipMemset(g_wave_dump, 0, bytes) != hipSuccess) {
@@ -524,7 +524,7 @@ void prepare_for_variant(cb_renderer *r, int kernel_variant) {
     }
   }
   if (!r->workspace_tried && (kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN)) != CB_KERNEL_SIMPLE &&
-      getenv("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
+      cb_debug_knob("CUDABROT_AMD_NO_WORKSPACE") == nullptr) {
     // scatter workspace for the largest launch render_passes makes; on any failure: direct atomics
     r->workspace_tried = 1;
     size_t want = cb_scatter_workspace_bytes_channels(&r->dims, r->n_channels > 0 ? r->n_channels : 1, r->n_threads,
@@ -579,7 +579,7 @@ int cb_renderer_render_passes(cb_renderer *r, uint32_t passes, int kernel_varian
     const size_t n = (size_t) cb::draw_wave_count(r->n_threads) * 8;
     std::vector<unsigned long long> host(n);
     if (hipMemcpy(host.data(), g_wave_dump, n * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-      if (FILE *f = fopen(getenv("CUDABROT_AMD_WAVE_DUMP"), "wb")) {
+      if (FILE *f = fopen(cb_debug_knob("CUDABROT_AMD_WAVE_DUMP"), "wb")) {
         fwrite(host.data(), 8, n, f);
         fclose(f);
       }
@@ -727,7 +727,7 @@ int cb_renderers_reduce(cb_renderer *const *renderers, int n) {
   if (n == 1) {
     // CUDABROT_AMD_FORCE_RCCL=1 (test knob): a reduce over one rank, to exercise the RCCL calls where
     // only one device exists
-    return getenv("CUDABROT_AMD_FORCE_RCCL") ? rccl_reduce_to_root(renderers, 1, count) : 0;
+    return cb_debug_knob("CUDABROT_AMD_FORCE_RCCL") ? rccl_reduce_to_root(renderers, 1, count) : 0;
   }
   bool same = true, distinct = true;
   for (int a = 0; a < n; ++a) {

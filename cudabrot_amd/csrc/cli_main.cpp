@@ -13,7 +13,8 @@
 //  * reference passes (512*512 threads x 50 samples) are fused into launches of about 0.2 s, so -t and
 //    Ctrl+C act at launch granularity; the printed pass count still counts reference-sized passes;
 //  * extension flags, which the reference answers with its usage text: --passes N, --kernel NAME,
-//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship, --channel MAX:MIN:FILE, --gpus N.
+//    --stats, --tonemap FORM, --seed N, --rng-state FILE, --burning-ship, --channel MAX:MIN:FILE, --gpus N,
+//    --state-format native|raw (raw: the -s file as the reference's bare buffer, uint32 when every count fits).
 #include <errno.h>
 #include <signal.h>
 #include <stdint.h>
@@ -54,6 +55,8 @@ struct Settings {
   bool bad_channel = false;
   uint64_t seed = CB_DEFAULT_RNG_SEED;              // --seed (extension; cudabrot.cu:37)
   const char *rng_state_file = nullptr;             // --rng-state (extension): true-resume sidecar
+  bool raw_state = false;                           // --state-format raw (extension): -s as the reference's bare buffer
+  bool bad_state_format = false;
   int tone_mode = CB_TONE_AUTO;                     // --tonemap (extension): device table / thresholds
   bool host_tonemap = false;                        //   ... or the reference's host loop
 };
@@ -185,6 +188,11 @@ const std::vector<Flag> &flag_table() {
        [](Settings &s, long i, double, const char *) { s.seed = (uint64_t) i; }},
       {"--rng-state", Value::kText, nullptr, false,
        [](Settings &s, long, double, const char *t) { s.rng_state_file = t; }},
+      {"--state-format", Value::kText, nullptr, false,
+       [](Settings &s, long, double, const char *t) {
+         s.raw_state = strcmp(t, "raw") == 0;
+         s.bad_state_format = !s.raw_state && strcmp(t, "native") != 0;
+       }},
       {"--tonemap", Value::kText, nullptr, false,
        [](Settings &s, long, double, const char *t) {
          s.host_tonemap = strcmp(t, "host") == 0;
@@ -256,6 +264,10 @@ Settings parse_arguments(int argc, char **argv) {
     flag->store(s, as_int, as_double, text);
     if (s.bad_channel) {
       printf("Invalid channel (want MAX:MIN:FILE, at most %d of them): %s\n", CB_MAX_CHANNELS, text);
+      usage_and_exit(argv[0]);
+    }
+    if (s.bad_state_format) {
+      printf("Invalid state format (want native or raw): %s\n", text);
       usage_and_exit(argv[0]);
     }
     if (flag->revalidates_canvas && !canvas_ok(s)) usage_and_exit(argv[0]);
@@ -354,7 +366,7 @@ class Run {
     cpu_mib /= (1024.0 * 1024.0);
     printf("Approximate memory needed: %.03f MiB GPU, %.03f MiB CPU\n", gpu_mib, cpu_mib);
     // CUDABROT_AMD_FAKE_GPUS=1: every rank on device -d (rehearsal of --gpus on a one-GPU box)
-    const bool fake = getenv("CUDABROT_AMD_FAKE_GPUS") != nullptr;
+    const bool fake = cb_debug_knob("CUDABROT_AMD_FAKE_GPUS") != nullptr;
     for (int r = 0; r < cfg_.gpus; ++r) {
       cb_renderer *one = nullptr;
       const int device = cfg_.device + (fake ? 0 : r);
@@ -386,7 +398,8 @@ class Run {
   void load_inprogress() {  // cudabrot.cu:215-258; the file work is state_files.cpp's
     if (!cfg_.inprogress_file) return;
     const cb::FileResult res = cb::load_state_file(cfg_.inprogress_file, (uint32_t) cfg_.canvas.w, (uint32_t) cfg_.canvas.h,
-                                                   (uint32_t) planes(), counts_);
+                                                   (uint32_t) planes(), counts_,
+                                                   cfg_.raw_state ? cb::StateFormat::kRaw : cb::StateFormat::kNative);
     if (res == cb::FileResult::kError) die();
     if (res == cb::FileResult::kOk) CB_CHECK(cb_renderer_write_histogram(renderer_, counts_));
   }
@@ -394,7 +407,8 @@ class Run {
   void save_inprogress() {  // cudabrot.cu:262-280
     if (!cfg_.inprogress_file) return;
     if (cb::save_state_file(cfg_.inprogress_file, (uint32_t) cfg_.canvas.w, (uint32_t) cfg_.canvas.h, (uint32_t) planes(),
-                            counts_) == cb::FileResult::kError) {
+                            counts_, cfg_.raw_state ? cb::StateFormat::kRaw : cb::StateFormat::kNative) ==
+        cb::FileResult::kError) {
       die();
     }
   }

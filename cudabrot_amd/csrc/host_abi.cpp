@@ -2,6 +2,8 @@
 // capi.hip so that the sanitized CPU build (tests/asan) links them without the HIP runtime.
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/cudabrot_amd.h"
 
@@ -26,6 +28,15 @@ int cb_recompute_pixel_deltas(cb_fractal_dimensions *dims, const char **msg) {
   dims->delta_imag = (dims->max_imag - dims->min_imag) / ((double) dims->h);
   dims->delta_real = (dims->max_real - dims->min_real) / ((double) dims->w);
   return 1;
+}
+
+// The one gate of the test / tuning knobs ("Diagnostics and test knobs"): a CUDABROT_AMD_* variable is
+// read only when CUDABROT_AMD_DEBUG=1 is set as well, so a stray variable in a user's environment cannot change
+// the path the product takes.
+const char *cb_debug_knob(const char *name) {
+  const char *gate = getenv("CUDABROT_AMD_DEBUG");
+  if (!gate || strcmp(gate, "1") != 0 || !name) return nullptr;
+  return getenv(name);
 }
 
 size_t cb_rng_state_bytes(uint32_t n_threads) { return (size_t) n_threads * 6u * sizeof(uint32_t); }

@@ -779,12 +779,12 @@ Shape shape_of(int w, int h, uint32_t planes) {
   s.tiles_y = tiles_y;
   s.n_tiles = (uint32_t) n;
   s.two_level = n > kGroupTiles ? 1u : 0u;
-  if (const char *e = getenv("CUDABROT_AMD_TWO_LEVEL")) {  // test knob: two levels on a small canvas
+  if (const char *e = cb_debug_knob("CUDABROT_AMD_TWO_LEVEL")) {  // test knob: two levels on a small canvas
     if (atoi(e) != 0) s.two_level = 1u;
   }
   s.n_groups = (s.n_tiles + kGroupTiles - 1u) / kGroupTiles;
   s.chunked = (s.two_level && s.n_groups <= kChunkedGroupsMax) ? 1u : 0u;
-  if (const char *e = getenv("CUDABROT_AMD_CHUNKED")) {  // test knob: 0 = level A as a counting sort over the stream
+  if (const char *e = cb_debug_knob("CUDABROT_AMD_CHUNKED")) {  // test knob: 0 = level A as a counting sort over the stream
     if (atoi(e) == 0) s.chunked = 0u;
   }
   return s;
@@ -834,7 +834,7 @@ T *carve(uintptr_t &p, size_t bytes) {
 }
 
 uint32_t slice_regions_setting() {
-  if (const char *e = getenv("CUDABROT_AMD_SLICE")) {  // tuning knob: regions per accumulate workgroup
+  if (const char *e = cb_debug_knob("CUDABROT_AMD_SLICE")) {  // tuning knob: regions per accumulate workgroup
     const long v = atol(e);
     if (v >= 1 && v <= (1l << 24)) return (uint32_t) v;
   }

@@ -24,7 +24,8 @@ struct File {  // closes on every path out
 
 }  // namespace
 
-FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, cb_pixel *counts) {
+FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, cb_pixel *counts,
+                           StateFormat format) {
   const uint64_t pixels = (uint64_t) w * (uint64_t) h;
   const uint64_t native_bytes = (uint64_t) planes * pixels * sizeof(cb_pixel);
   File in(fopen(path, "rb"));
@@ -77,9 +78,12 @@ FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t pl
       ok = fread(row.data(), sizeof(uint32_t), w, in.f) == w;
       for (uint32_t c = 0; ok && c < w; ++c) counts[r * w + c] = row[c];
     }
+  } else if (format == StateFormat::kRaw && (uint64_t) size == native_bytes) {
+    printf("%s has no header and the size of 64-bit counters: read as raw 64-bit counters.\n", path);
+    ok = fseek(in.f, 0, SEEK_SET) == 0 && (native_bytes == 0 || fread(counts, native_bytes, 1, in.f) == 1);
   } else {
     printf("The size of %s doesn't match the expected size of %lu bytes.\n", path,
-           (unsigned long) (sizeof(hd) + native_bytes));
+           (unsigned long) (format == StateFormat::kRaw ? native_bytes : sizeof(hd) + native_bytes));
     return FileResult::kError;
   }
   if (!ok) {
@@ -89,13 +93,36 @@ FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t pl
   return FileResult::kOk;
 }
 
-FileResult save_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, const cb_pixel *counts) {
+FileResult save_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, const cb_pixel *counts,
+                           StateFormat format) {
   const uint64_t native_bytes = (uint64_t) planes * (uint64_t) w * (uint64_t) h * sizeof(cb_pixel);
   printf("Saving in-progress buffer to %s.\n", path);  // cudabrot.cu:265
   File out(fopen(path, "wb"));
   if (!out.f) {
     printf("Failed opening %s: %s\n", path, strerror(errno));
     return FileResult::kError;
+  }
+  if (format == StateFormat::kRaw) {  // the reference's file: bare counters (cudabrot.cu:262-280)
+    const uint64_t n = (uint64_t) planes * (uint64_t) w * (uint64_t) h;
+    bool narrow = planes == 1;
+    for (uint64_t k = 0; narrow && k < n; ++k) narrow = counts[k] <= 0xffffffffull;
+    bool ok = true;
+    if (narrow) {  // uint32[h][w], what the reference's LoadInProgressBuffer expects (cudabrot.cu:236-245)
+      std::vector<uint32_t> row(w);
+      for (uint64_t r = 0; ok && r < h; ++r) {
+        for (uint32_t c = 0; c < w; ++c) row[c] = (uint32_t) counts[r * w + c];
+        ok = w == 0 || fwrite(row.data(), sizeof(uint32_t), w, out.f) == w;
+      }
+    } else {
+      printf("%s: raw 64-bit counters (%s): not a file the reference can load.\n", path,
+             planes == 1 ? "a count exceeds 32 bits" : "more than one plane");
+      ok = native_bytes == 0 || fwrite(counts, native_bytes, 1, out.f) == 1;
+    }
+    if (!ok) {
+      printf("Failed writing data to %s: %s\n", path, strerror(errno));  // cudabrot.cu:275-277
+      return FileResult::kError;
+    }
+    return FileResult::kOk;
   }
   StateHeader hd;
   memset(&hd, 0, sizeof(hd));

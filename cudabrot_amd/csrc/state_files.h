@@ -29,8 +29,16 @@ struct StateHeader {
 };
 static_assert(sizeof(StateHeader) == 32, "the -s header is 32 bytes");
 
-FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, cb_pixel *counts);
-FileResult save_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, const cb_pixel *counts);
+// --state-format raw (default: native, the header above): the file is the bare counters, as the reference writes it
+// (cudabrot.cu:262-280) -- uint32[h][w] when there is one plane and every count fits 32 bits, so that the reference
+// (or a script that np.fromfile()s the buffer) reads it back; else uint64, announced.  On load, raw accepts a
+// headerless file of exactly the 32-bit or the 64-bit size (with an explicit flag the size is not a guess).
+enum class StateFormat { kNative, kRaw };
+
+FileResult load_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, cb_pixel *counts,
+                           StateFormat format = StateFormat::kNative);
+FileResult save_state_file(const char *path, uint32_t w, uint32_t h, uint32_t planes, const cb_pixel *counts,
+                           StateFormat format = StateFormat::kNative);
 
 // The sidecar: this header, then for every rank {uint64 first_subsequence = rank * n_threads,
 // cb_rng_state_bytes(n_threads) bytes}.  With --gpus N it holds N generators and resumes only an N-GPU run.

@@ -274,6 +274,12 @@ int cb_renderer_grayscale_plane(cb_renderer *r, int plane, double gamma, int mod
 const char *cb_error_string(int code);
 int cb_abi_version(void);
 
+/* Diagnostics.  The library's test and tuning knobs are environment variables named CUDABROT_AMD_* (DESIGN.md
+ * section 7 lists them; none is needed in normal use, all are result-neutral).  They are read through this one
+ * gate: the value of `name`, or NULL unless CUDABROT_AMD_DEBUG=1 is set too -- a stray variable in a user's
+ * environment cannot change the path the product takes.  (The reference has no such knobs.) */
+const char *cb_debug_knob(const char *name);
+
 #ifdef __cplusplus
 }
 #endif

@@ -112,6 +112,44 @@ void test_state_files(const std::string &dir) {
     EXPECT(planes == back);
     EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data()) == FileResult::kError);
   }
+  // --state-format raw: the reference's bare buffer (cudabrot.cu:262-280).  uint32 when every count fits ...
+  {
+    using cb::StateFormat;
+    std::vector<cb_pixel> small((size_t) w * h), back((size_t) w * h, 3);
+    for (auto &v : small) v = (uint32_t) rnd();
+    small[5] = 0xffffffffull;  // the largest count that still fits
+    EXPECT(cb::save_state_file(p.c_str(), w, h, 1, small.data(), StateFormat::kRaw) == FileResult::kOk);
+    std::vector<unsigned char> raw = slurp(p);
+    EXPECT(raw.size() == small.size() * 4);
+    for (size_t i = 0; i < small.size(); ++i) {
+      uint32_t v;
+      memcpy(&v, raw.data() + 4 * i, 4);
+      EXPECT(v == (uint32_t) small[i]);
+    }
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(small == back);
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data()) == FileResult::kOk);  // also without the flag (announced)
+    // ... uint64 once a count does not fit, or with several planes: only --state-format raw reads that back
+    small[7] = 0x100000000ull;
+    EXPECT(cb::save_state_file(p.c_str(), w, h, 1, small.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(slurp(p).size() == small.size() * 8);
+    std::fill(back.begin(), back.end(), 3);
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data()) == FileResult::kError);  // headerless 64-bit: never guessed
+    EXPECT(back[0] == 3);
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(small == back);
+    EXPECT(cb::load_state_file(p.c_str(), w + 1, h, 1, back.data(), StateFormat::kRaw) == FileResult::kError);
+    std::vector<cb_pixel> planes((size_t) w * h * 2), pback((size_t) w * h * 2);
+    for (auto &v : planes) v = (uint32_t) rnd();
+    EXPECT(cb::save_state_file(p.c_str(), w, h, 2, planes.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(slurp(p).size() == planes.size() * 8);
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 2, pback.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(planes == pback);
+    // a native file is still recognised by its magic under the flag
+    EXPECT(cb::save_state_file(p.c_str(), w, h, 1, a.data()) == FileResult::kOk);
+    EXPECT(cb::load_state_file(p.c_str(), w, h, 1, back.data(), StateFormat::kRaw) == FileResult::kOk);
+    EXPECT(a == back);
+  }
   // unwritable / unreadable paths
   EXPECT(cb::save_state_file((dir + "/no/such/dir/x").c_str(), w, h, 1, a.data()) == FileResult::kError);
   EXPECT(cb::load_state_file(dir.c_str(), w, h, 1, b.data()) == FileResult::kError);  // a directory

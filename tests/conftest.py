@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The product reads its test / tuning knobs (CUDABROT_AMD_TWO_LEVEL, ..._NO_WORKSPACE, ..._FAKE_GPUS, ...) only behind
+# this gate (cb_debug_knob, include/cudabrot_amd.h); the suite drives those knobs, so it opens the gate for itself and
+# for the processes it starts.  tests/test_capi_host.py checks that a knob is ignored without it.
+os.environ["CUDABROT_AMD_DEBUG"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

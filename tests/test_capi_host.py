@@ -24,6 +24,27 @@ def test_library_exports_every_declared_symbol(cb, repo_root):
     assert cb.lib.cb_abi_version() == 1
 
 
+def test_knobs_are_read_only_behind_the_debug_gate(cb, monkeypatch):
+    """A stray CUDABROT_AMD_* variable must not change the product's path: every knob goes through cb_debug_knob,
+    which answers only when CUDABROT_AMD_DEBUG=1 is set as well."""
+    monkeypatch.setenv("CUDABROT_AMD_NO_WORKSPACE", "1")
+    monkeypatch.delenv("CUDABROT_AMD_DEBUG", raising=False)
+    assert cb.lib.cb_debug_knob(b"CUDABROT_AMD_NO_WORKSPACE") is None
+    monkeypatch.setenv("CUDABROT_AMD_DEBUG", "0")
+    assert cb.lib.cb_debug_knob(b"CUDABROT_AMD_NO_WORKSPACE") is None
+    monkeypatch.setenv("CUDABROT_AMD_DEBUG", "1")
+    assert cb.lib.cb_debug_knob(b"CUDABROT_AMD_NO_WORKSPACE") == b"1"
+    assert cb.lib.cb_debug_knob(b"CUDABROT_AMD_TWO_LEVEL") is None
+    # and no product source reads the environment any other way
+    import glob
+    root = os.path.dirname(os.path.dirname(cb.library_path()))
+    for f in glob.glob(os.path.join(root, "cudabrot_amd", "csrc", "*.*")):
+        text = open(f).read()
+        if f.endswith("host_abi.cpp"):
+            continue
+        assert "getenv(" not in text, f
+
+
 def test_struct_layouts_match_the_reference_kernel_arguments(cb):
     # FractalDimensions is 56 bytes, IterationControl 8 (cudabrot.cu:46-67; SURVEY.md section 2)
     assert C.sizeof(cb.FractalDimensions) == 56

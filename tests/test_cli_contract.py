@@ -52,6 +52,8 @@ def test_help_prints_usage_and_exits_zero(exe):
         # extension flags follow the same conventions
         (["--gpus"], "Argument --gpus needs a value."),
         (["--passes", "many"], "Invalid number given to argument --passes: many"),
+        (["--state-format", "json"], "Invalid state format (want native or raw): json"),
+        (["--state-format"], "Argument --state-format needs a value."),
         (["--channel", "100:20"], "Invalid channel (want MAX:MIN:FILE, at most 4 of them): 100:20"),
         (["--channel", "a:b:c"], "Invalid channel (want MAX:MIN:FILE, at most 4 of them): a:b:c"),
         (["--channel", "9:1:a", "--channel", "9:1:b", "--channel", "9:1:c", "--channel", "9:1:d", "--channel", "9:1:e"],

@@ -163,6 +163,30 @@ def test_reference_format_u32_buffer_is_accepted_and_widened(exe, small_render, 
     assert np.array_equal(state, base.astype(np.uint64) + small_render[0])
 
 
+def test_state_format_raw_writes_the_buffer_the_reference_reads(exe, small_render, tmp_path):
+    """--state-format raw: the -s file is the reference's own format again -- bare uint32[h][w], no header
+    (cudabrot.cu:262-280) -- so a buffer can go BACK to the reference binary (or to np.fromfile); resuming from it
+    adds to it like the reference does (cudabrot.cu:215-258)."""
+    buf = str(tmp_path / "raw_state.bin")
+    args = ("-w", "300", "-h", "200", "-m", "200", "-o", os.devnull, "-s", buf, "--state-format", "raw")
+    r = run(exe, "--passes", "2", *args)
+    assert r.returncode == 0
+    assert os.path.getsize(buf) == 300 * 200 * 4                      # what LoadInProgressBuffer checks, :236-245
+    first = np.fromfile(buf, dtype=np.uint32).reshape(200, 300)
+    assert np.array_equal(first.astype(np.uint64), small_render[0])
+    r = run(exe, "--passes", "2", *args)                                # resume: seed 1337 again, like the reference
+    assert r.returncode == 0 and "read as the reference's format" in r.stdout
+    second = np.fromfile(buf, dtype=np.uint32).reshape(200, 300)
+    assert np.array_equal(second.astype(np.uint64), 2 * small_render[0])
+    # a count beyond 32 bits cannot be written narrow: raw 64-bit counters, announced, read back under the flag
+    big = small_render[0].copy()
+    big[3, 4] = 1 << 40
+    big.astype(np.uint64).tofile(buf)
+    r = run(exe, "--passes", "0", *args)
+    assert r.returncode == 0 and "read as raw 64-bit counters" in r.stdout and "not a file the reference can load" in r.stdout
+    assert np.array_equal(np.fromfile(buf, dtype=np.uint64).reshape(200, 300), big)
+
+
 def test_native_buffer_of_another_canvas_is_refused_even_at_the_reference_size(exe, tmp_path):
     """A native (u64) buffer of HALF the pixel count has exactly w*h*4 bytes of payload for this canvas: the
     format is decided by the header, never by the size, so it is refused with the reference's size-mismatch

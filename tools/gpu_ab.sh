@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timings of the CLI at the BASELINE shapes; prints passes, samples/s and (timed variant) stage stamps.
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 mkdir -p gpurun_out
 one() {  # one <label> <env...> -- <args...>
   local label=$1; shift

@@ -2,6 +2,7 @@
 # On the GPU box: for every exported state (tools/ab_export.sh), rebuild and print two bench lines (C3) and one
 # fixed-pass run of the reference's default canvas.  Alternate the names (a b a b) to see the box's own drift.
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 mkdir -p gpurun_out
 for v in "$@"; do
   cp tools/_ab/$v/* cudabrot_amd/csrc/

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the LONG stage's chunk length (kernels.h CB_CHUNK): rebuilds on the GPU box per value.
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 mkdir -p gpurun_out
 for L in "$@"; do
   sed -i "s/^#define CB_CHUNK .*/#define CB_CHUNK $L/" cudabrot_amd/csrc/kernels.h

@@ -2,6 +2,7 @@
 # Same-box sweep of compile-time constants of draw_wave.hip: tools/gpu_draw_sweep.sh "-DCB_REPLAY_MIN=40" "-DCB_REPLAY_MIN=48" ...
 # For each flag set: rebuild the draw kernel objects, then sequential draw timings at C3 (and C2).
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 for flags in "$@"; do
   echo "#### EXTRA=$flags"
   rm -f cudabrot_amd/csrc/build/*.o

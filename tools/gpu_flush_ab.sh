@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of scatter tuning knobs: bench lines (draw ms, scatter ms, value) per setting.
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 mkdir -p gpurun_out
 for v in "$@"; do
   log=gpurun_out/flush_ab_$(echo "$v" | tr '= ' '__').json

@@ -15,6 +15,8 @@ and demands identical histograms and counters.
                                                    against direct atomics of the same kernel
 """
 import os
+
+os.environ["CUDABROT_AMD_DEBUG"] = "1"  # the knobs below are read only behind this gate (cb_debug_knob)
 import random
 import sys
 import time

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Same-box sweep of the level-A replica count of the two-level sort (scatter.hip kReplicas) at C4.
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 mkdir -p gpurun_out
 for R in "$@"; do
   sed -i "s/^constexpr uint32_t kReplicas = [0-9]*;/constexpr uint32_t kReplicas = $R;/" cudabrot_amd/csrc/scatter.hip

@@ -2,6 +2,7 @@
 # Same-box sweep of compile-time constants of scatter.hip: tools/gpu_scatter_sweep.sh "-DCB_CNT_REPLICAS=2" "-DCB_CNT_REPLICAS=3" ...
 # For each flag set: rebuild scatter.o + the library, then the sequential per-kernel timings of C3 (CFGS overrides).
 set -u
+export CUDABROT_AMD_DEBUG=1   # the CUDABROT_AMD_* knobs are read only behind this gate (cb_debug_knob)
 for flags in "$@"; do
   echo "#### EXTRA=$flags  SLICE=${CUDABROT_AMD_SLICE:-default}"
   rm -f cudabrot_amd/csrc/build/scatter.o
