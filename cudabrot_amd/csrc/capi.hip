@@ -279,8 +279,20 @@ int rccl_reduce_to_root(cb_renderer *const *renderers, int n, size_t count) {
   }
   std::vector<int> devices(n);
   for (int k = 0; k < n; ++k) devices[k] = renderers[k]->device;
-  std::vector<ncclComm_t> comms(n);
-  if (comm_init_all(comms.data(), n, devices.data()) != ncclSuccess) return (int) hipErrorUnknown;
+  // One communicator per set of devices, kept for the life of the process: creating it costs far more than the
+  // reduce (a bootstrap over all ranks), and a renderer set is reduced at every checkpoint.
+  static std::vector<int> comm_devices;
+  static std::vector<ncclComm_t> comms;
+  if (comm_devices != devices) {
+    for (ncclComm_t c : comms) (void) comm_destroy(c);
+    comms.assign((size_t) n, nullptr);
+    comm_devices.clear();
+    if (comm_init_all(comms.data(), n, devices.data()) != ncclSuccess) {
+      comms.clear();
+      return (int) hipErrorUnknown;
+    }
+    comm_devices = devices;
+  }
   ncclResult_t nr = group_start();
   for (int k = 0; k < n && nr == ncclSuccess; ++k) {
     if (hipSetDevice(devices[k]) != hipSuccess) {
@@ -298,7 +310,11 @@ int rccl_reduce_to_root(cb_renderer *const *renderers, int n, size_t count) {
     const hipError_t e = hipStreamSynchronize(renderers[k]->stream);
     if (e != hipSuccess && rc == 0) rc = (int) e;
   }
-  for (int k = 0; k < n; ++k) (void) comm_destroy(comms[k]);
+  if (rc != 0) {  // a communicator that has failed is not reused
+    for (ncclComm_t c : comms) (void) comm_destroy(c);
+    comms.clear();
+    comm_devices.clear();
+  }
   return rc;
 }
 

@@ -23,7 +23,10 @@
 #include <string.h>
 #include <time.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -466,29 +469,20 @@ class Run {
     CB_CHECK(cb_renderer_prepare(renderer_, variant));
     for (cb_renderer *p : peers_) CB_CHECK(cb_renderer_prepare(p, variant));
     const double t0 = wall_seconds();
-    // The pass loop (one iteration = one batch of `next` reference passes on EVERY rank).  The main thread
-    // alone reads the clock and the quit flag and sizes the batches, so all ranks render the same number of
-    // passes -- an N-GPU run is the documented "N T threads for P passes" whether it ends by --passes, -t or
-    // Ctrl+C -- and a device error on any rank is reported here, after every worker has been joined.
+    // The pass loop.  One GPU: batches of `next` reference passes, sized so that the clock and the quit flag are
+    // looked at every ~0.2 s.  --gpus N: render_sharded (persistent rank threads and a shared pass budget).
     const double launch_seconds = 0.2;
     long done = 0, next = 1;  // passes per rank
-    std::vector<int> rank_rc((size_t) cfg_.gpus, 0);
+    if (cfg_.gpus > 1) {
+      done = render_sharded(variant, by_clock, t0);
+    } else {
     while (!g_quit_requested) {
       if (!by_clock) {
         if (done >= cfg_.fixed_passes) break;
         next = cfg_.fixed_passes - done;
         if (next > 256) next = 256;
       }
-      std::vector<std::thread> workers;
-      for (size_t k = 0; k < peers_.size(); ++k) {
-        workers.emplace_back([&, k] { rank_rc[k + 1] = cb_renderer_render_passes(peers_[k], (uint32_t) next, variant); });
-      }
-      rank_rc[0] = cb_renderer_render_passes(renderer_, (uint32_t) next, variant);
-      for (std::thread &w : workers) w.join();
-      for (int r = 0; r < cfg_.gpus; ++r) {
-        if (rank_rc[(size_t) r] != 0 && cfg_.gpus > 1) printf("GPU %d of %d:\n", r, cfg_.gpus);
-        CB_CHECK(rank_rc[(size_t) r]);
-      }
+      CB_CHECK(cb_renderer_render_passes(renderer_, (uint32_t) next, variant));
       done += next;
       if (!by_clock) continue;
       const double elapsed = wall_seconds() - t0;
@@ -502,6 +496,7 @@ class Run {
       if (next < 1) next = 1;
       if (next > 4096) next = 4096;
       if (next > 128) next -= next % 128;  // whole launches of 128 passes (cb_renderer's): a short launch drains badly
+    }
     }
     passes_this_run_ = (uint64_t) done;  // per rank: what the generators have consumed
     done *= cfg_.gpus;                   // reference-sized passes over all ranks
@@ -519,6 +514,119 @@ class Run {
     if (cfg_.print_stats) print_stats();
     if (cfg_.n_channels == 0) tone_map(0);
   }
+
+  // The pass loop of --gpus N.  One persistent host thread per rank; the ranks do not meet at batch
+  // ends (boxes differ by 3-4 %, and every rendezvous would cost the faster ranks that much plus a restart of their
+  // pipelines).  What they share is a pass BUDGET: `granted`, raised by the main thread alone -- which alone reads
+  // the clock and the quit flag -- about 0.4 s ahead of the slowest rank; a rank renders whatever the budget allows
+  // beyond its own count, in whole launches.  When the run ends (--passes reached, -t over, Ctrl+C) the budget is
+  // frozen at what the furthest rank has been given and every rank completes it: an N-GPU run is "N T threads for
+  // P passes" however it ends, which is what makes it reproducible and resumable (--rng-state).  A device error on
+  // any rank stops the budget; it is reported from the main thread after every worker has been joined.
+  long render_sharded(int variant, bool by_clock, double t0) {
+    const int n = cfg_.gpus;
+    struct Shared {
+      std::mutex m;
+      std::condition_variable cv;
+      long granted = 0;
+      bool closed = false;            // the budget is final
+      std::vector<long> done, taken;  // per rank: passes rendered / rendered + in flight
+      std::vector<int> rc;
+    } sh;
+    sh.done.assign((size_t) n, 0);
+    sh.taken.assign((size_t) n, 0);
+    sh.rc.assign((size_t) n, 0);
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n; ++k) {
+      workers.emplace_back([&, k] {
+        cb_renderer *mine = rank_renderer(k);
+        for (;;) {
+          long piece = 0;
+          {
+            std::unique_lock<std::mutex> lock(sh.m);
+            sh.cv.wait(lock, [&] { return sh.granted > sh.done[(size_t) k] || sh.closed; });
+            piece = sh.granted - sh.done[(size_t) k];
+            if (piece <= 0) return;       // closed and complete
+            if (piece > 1024) piece = 1024;  // (a call returns when its launches are done: look at the budget again)
+            sh.taken[(size_t) k] = sh.done[(size_t) k] + piece;
+          }
+          const int rc = cb_renderer_render_passes(mine, (uint32_t) piece, variant);
+          std::lock_guard<std::mutex> lock(sh.m);
+          if (rc != 0) {
+            sh.rc[(size_t) k] = rc;
+            sh.taken[(size_t) k] = sh.done[(size_t) k];
+            sh.closed = true;             // no further grants; the others finish what they have taken
+            sh.granted = 0;
+            for (int j = 0; j < n; ++j) sh.granted = sh.taken[(size_t) j] > sh.granted ? sh.taken[(size_t) j] : sh.granted;
+            sh.cv.notify_all();
+            return;
+          }
+          sh.done[(size_t) k] += piece;
+          sh.cv.notify_all();
+        }
+      });
+    }
+    {
+      std::unique_lock<std::mutex> lock(sh.m);
+      const long lead_min = 128;  // whole launches of cb_renderer (a short launch drains badly)
+      if (!by_clock) {
+        sh.granted = cfg_.fixed_passes > 0 ? cfg_.fixed_passes : 0;
+        if (sh.granted == 0) sh.closed = true;
+      } else {
+        sh.granted = 1;  // the first pass calibrates the pace
+      }
+      sh.cv.notify_all();
+      for (;;) {
+        bool failed = false;
+        long slowest = sh.granted, furthest = 0;
+        for (int k = 0; k < n; ++k) {
+          failed = failed || sh.rc[(size_t) k] != 0;
+          slowest = sh.done[(size_t) k] < slowest ? sh.done[(size_t) k] : slowest;
+          furthest = sh.taken[(size_t) k] > furthest ? sh.taken[(size_t) k] : furthest;
+        }
+        if (failed || sh.closed) break;
+        const double elapsed = wall_seconds() - t0;
+        const bool time_up = by_clock && cfg_.seconds_to_run >= 0 && elapsed > cfg_.seconds_to_run && slowest >= 1;
+        const bool all_done = !by_clock && slowest >= sh.granted;
+        if (g_quit_requested || time_up || all_done) {
+          // final budget: what the furthest rank has been given (at least one pass, like the reference's loop)
+          sh.granted = furthest > 1 ? furthest : 1;
+          if (!by_clock && !g_quit_requested) sh.granted = cfg_.fixed_passes;
+          sh.closed = true;
+          sh.cv.notify_all();
+          break;
+        }
+        if (by_clock && slowest >= 1) {
+          const double per_pass = elapsed / (double) slowest;  // the slowest rank's pace
+          double ahead = 2.0 * launch_seconds_;
+          if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < ahead) ahead = cfg_.seconds_to_run - elapsed;
+          long lead = per_pass > 0 ? (long) (ahead / per_pass) : lead_min;
+          if (lead > 4096) lead = 4096;
+          if (lead > lead_min) lead -= lead % lead_min;
+          if (lead < 1) lead = 1;
+          if (slowest + lead > sh.granted) {
+            sh.granted = slowest + lead;
+            sh.cv.notify_all();
+          }
+        }
+        sh.cv.wait_for(lock, std::chrono::milliseconds(10));
+      }
+      // every rank completes the final budget
+      sh.cv.wait(lock, [&] {
+        for (int k = 0; k < n; ++k) {
+          if (sh.rc[(size_t) k] == 0 && sh.done[(size_t) k] < sh.granted) return false;
+        }
+        return true;
+      });
+    }
+    for (std::thread &w : workers) w.join();
+    for (int r = 0; r < n; ++r) {
+      if (sh.rc[(size_t) r] != 0) printf("GPU %d of %d:\n", r, n);
+      CB_CHECK(sh.rc[(size_t) r]);
+    }
+    return sh.granted;
+  }
+  static constexpr double launch_seconds_ = 0.2;
 
   void tone_map(int plane) {
     uint64_t max = 0;
