@@ -262,10 +262,10 @@ class Job:
         if self.windows:
             cb.draw_buddhabrot_channels(self.dims, self.hist.data_ptr(), self.windows, self.states.data_ptr(),
                                         self.threads, samples, self.counters.data_ptr(), variant,
-                                        stream or self.stream, ws, self.ws_bytes, carry.data_ptr())
+                                        self.stream if stream is None else stream, ws, self.ws_bytes, carry.data_ptr())
         else:
             cb.draw_buddhabrot(self.dims, self.hist.data_ptr(), self.it, self.states.data_ptr(), self.threads, samples,
-                               self.counters.data_ptr(), variant, stream or self.stream, ws, self.ws_bytes,
+                               self.counters.data_ptr(), variant, self.stream if stream is None else stream, ws, self.ws_bytes,
                                carry.data_ptr())
 
     def flush(self, k, stream=None):
@@ -274,10 +274,11 @@ class Job:
             return
         if self.windows:
             cb.flush_scatter_channels(self.dims, self.hist.data_ptr(), self.planes, self.threads,
-                                      self.workspaces[k].data_ptr(), self.ws_bytes, stream or self.flush_stream)
+                                      self.workspaces[k].data_ptr(), self.ws_bytes,
+                                      self.flush_stream if stream is None else stream)
         else:
             cb.flush_scatter(self.dims, self.hist.data_ptr(), self.threads, self.workspaces[k].data_ptr(), self.ws_bytes,
-                             stream or self.flush_stream)
+                             self.flush_stream if stream is None else stream)
 
     def step(self, samples=None, ev_draw=None, ev_flush=None):
         """One launch of the dominant kernel (sample -> iterate -> replay, cudabrot.cu:379-414) on the draw
@@ -336,7 +337,7 @@ class Job:
         return draw_ms, flush_ms, incr
 
 
-def other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread, steps=6):
+def other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread, steps=12):
     """A short leg of another BASELINE.json config, BEFORE the clock of the headline workload and not part of
     `value`: Msamples/s of `steps` pipelined launches + the drain launch (wall clock between device syncs, one warm-up
     step first), and the draw launch / the scatter kernels alone.  The histogram is checked against the in-kernel

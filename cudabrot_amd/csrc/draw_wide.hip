@@ -1,0 +1,1342 @@
+// draw_wide.hip -- draw_wide_kernel: the product path of DrawBuddhabrot (cudabrot.cu:379-414) for the usual
+// configuration, shaped so that it fills the fp64 pipe from TWO waves per SIMD and leaves the other half of every
+// CU (256 vector registers per SIMD lane, ~80 KiB of LDS) to the scatter kernels of the previous launch.
+//
+// Why.  The draw kernel is bound by vector issue, the scatter (scatter.hip) by memory; run one after the other a
+// step costs their sum.  draw_wave_kernel (draw_wave.hip) needs four waves per SIMD of 128 registers each to hide
+// the latency of its dependent fp64 chains, which fills the register file: nothing else can live on the CU.  This
+// kernel keeps the same four stages over the same three wave-private queues (read draw_wave.hip's header first)
+// but gets its latency hiding from instruction-level parallelism inside a wave instead of from more waves:
+//
+//   a wave owns 128 subsequences (two generators per lane, A and B), so the grid is 2048 waves = 2 per SIMD;
+//   HEAD    software-pipelined: the draw of sample n+1 (integer chain) is interleaved, instruction by instruction,
+//           with the cardioid / bulb test and the four iterations of sample n (fp64 chain); A and B alternate.
+//           EXEC stays full (the generator must advance in every lane), the survivors are tracked in scalar masks;
+//   MID     as in draw_wave.hip (one chain; 5 % of the instructions);
+//   LONG    FOUR orbits per lane, interleaved instruction by instruction (escape test once per chunk);
+//   REPLAY  software-pipelined: the pixel of point n is formed and stored while point n+1 is computed; a lane's
+//           state between bursts is "z_n computed, not yet recorded".
+//
+// Launched for: a scatter workspace of one level (canvases of up to 1024 tiles), one channel, the usual stage
+// split with min_iter == the start of the LONG stage (every BASELINE config with the default -c 20), a carry
+// buffer, n_threads a multiple of 512.  Everything else is draw_wave_kernel's (capi.hip picks; same results).
+//
+// Compiled with -ffp-contract=off; all coordinates DOUBLED (C = 2c, Z = 2z) as in draw_wave.hip; the arithmetic of
+// every step is device_math.h's mandel_step2, instruction for instruction.
+#include <stdlib.h>
+
+#include "draw_common.h"
+
+// Compiled twice like draw_wave.hip: as is, and with -DCB_BURNING_SHIP (cudabrot.cu:15-17).
+#ifdef CB_BURNING_SHIP
+#define CB_AL "|"
+#define CB_AR "|"
+#define CB_LAUNCH_NAME launch_draw_wide_ship
+#else
+#define CB_AL ""
+#define CB_AR ""
+#define CB_LAUNCH_NAME launch_draw_wide
+#endif
+
+namespace cb {
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kSlots = 4;              // deep orbits a lane iterates side by side in the LONG stage
+constexpr int kQ0Cap = 128;            // HEAD survivors: c            (2 KiB per wave)
+constexpr int kQ1Cap = 96;             // MID survivors: (c, z)        (3 KiB per wave)
+constexpr int kQ2Cap = 320;            // accepted starting points: c  (5 KiB per wave)
+constexpr int kHeadSteps = 4;
+#ifndef CB_WQ1_LOW
+#define CB_WQ1_LOW 32
+#endif
+#ifndef CB_WQ1_EXIT
+#define CB_WQ1_EXIT 8
+#endif
+#ifndef CB_WREPLAY_MIN
+#define CB_WREPLAY_MIN 56
+#endif
+#ifndef CB_WREPLAY_BURST
+#define CB_WREPLAY_BURST 32
+#endif
+constexpr int kQ1Low = CB_WQ1_LOW;      // run MID while fewer deep orbits than this are queued
+constexpr int kQ1Exit = CB_WQ1_EXIT;    // LONG hands over to HEAD / MID below this many
+constexpr int kReplayMin = CB_WREPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
+constexpr uint32_t kReplayBurst = CB_WREPLAY_BURST;  // replay steps per asm burst
+constexpr uint32_t kBrentBits = 2;      // periodicity check: re-save when the chunk count has no bits below its top 2
+constexpr uint32_t kPrioChunks = 16;    // LONG chunks between two looks at the progress board (power of two)
+
+// Ring capacities are exact worst cases (CB_STATUS_QUEUE_OVERFLOW guards the reasoning, these the constants):
+//   Q0: a HEAD half-pass runs while q0_count < 64 and pushes at most 64             -> 63 + 64
+//   Q1: MID runs while q1_count < kQ1Low and pushes at most 64                      -> kQ1Low - 1 + 64
+//   Q2: LONG runs while q2_count + replaying < 64; one chunk can retire every slot  -> 63 + 64 * kSlots
+static_assert(kQ0Cap >= 63 + 64, "Q0 must hold a full HEAD half-pass on top of 63 queued survivors");
+static_assert(kQ1Cap >= kQ1Low - 1 + 64, "Q1 must hold a full MID pass on top of kQ1Low - 1 queued orbits");
+static_assert(kQ2Cap >= 63 + 64 * kSlots, "Q2 must hold every orbit slot of a chunk on top of 63 queued points");
+
+struct WideQueues {
+  double q0_cr[kQ0Cap], q0_ci[kQ0Cap];
+  double q1_cr[kQ1Cap], q1_ci[kQ1Cap], q1_r[kQ1Cap], q1_i[kQ1Cap];
+  double q2_cr[kQ2Cap], q2_ci[kQ2Cap];
+};
+constexpr uint32_t kWideQueueWords = sizeof(WideQueues) / 8;
+// carry record of a wave: header, the queues, the lanes' planes (u64 each):
+//   LONG kSlots x {cr, ci, r, i, seen_r, seen_i}, l_rem[0..1], l_rem[2..3], REPLAY {cr, ci, r, i}, {p_start, p_act}
+constexpr uint32_t kWideLanePlanes = kSlots * 6 + 2 + 4 + 1;
+constexpr uint32_t kWideCarryWords = kCarryHeaderWords + kWideQueueWords + kWideLanePlanes * 64;
+static_assert(kWideCarryWords <= 2 * kCarryWordsPerWave, "a wide wave uses the carry records of the two waves it replaces");
+
+struct Orbit {
+  double cr, ci, r, i;
+};
+
+__device__ __forceinline__ bool lane_in(unsigned long long mask) {
+  return __builtin_amdgcn_inverse_ballot_w64(mask);
+}
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t) (v >> 32));
+  return ((unsigned long long) hi << 32) | lo;
+}
+
+typedef const DrawArgs __attribute__((address_space(4))) *KernelArgs;
+__device__ __forceinline__ KernelArgs fresh_args() {
+  KernelArgs p = (KernelArgs) __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+// ---- one orbit per lane under EXEC (MID, the last short chunk of LONG, the first and last HEAD sample) --------
+// (draw_wave.hip, CB_STEP: the six instructions of mandel_step2, the lane-step count, EXEC &= !(16 < |Z|^2))
+#define CB_STEP                                       \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, %[k16], %[a]\n\t"
+
+__device__ __forceinline__ unsigned long long iterate_steps(unsigned long long mask, uint32_t n,
+                                                            Orbit &o, uint32_t &lane_steps) {
+  unsigned long long save, escaped;
+  uint32_t cnt, tmp, ctr;
+  double a;
+  const double k16 = 16.0;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "1:\n\t"
+      CB_STEP
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_andn2_b64 %[esc], %[mask], exec\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [r] "+v"(o.r), [i] "+v"(o.i), [a] "=&v"(a), [save] "=&s"(save),
+        [esc] "=&s"(escaped), [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr)
+      : [mask] "s"(mask), [n] "s"(n), [cr] "v"(o.cr), [ci] "v"(o.ci), [k16] "s"(k16)
+      : "vcc", "scc");
+  lane_steps = cnt;
+  return escaped;
+}
+
+// ---- HEAD, software-pipelined -----------------------------------------------------------------------------------
+//
+// A HALF-PASS takes one sample per lane from ONE of the lane's two generators (cudabrot.cu:392-393, 398, 326-337):
+//   the draw    four XORWOW outputs (rocrand_xorwow.h:165-177) and the two starting coordinates (device_math.h,
+//               sample_coordinate2): an integer chain of ~20 dependent operations;
+//   the test    cardioid / bulb test (in_main_cardioid2, in_order2_bulb2) and the first four iterations: an fp64 chain
+//               of ~25 dependent operations; the survivors' c goes to Q0.
+// The two chains of ONE sample depend on each other, those of consecutive samples do not: a BODY of the loop below
+// tests the sample that is PENDING (drawn by the body before it, c in cr / ci) while it draws the next one from the
+// other generator, alternating the two instruction streams.  A body's text depends on which generator it draws from
+// and on the rotation of that generator's words (draw_wave.hip, CB_HEAD_DRAW: logical word j lives in field
+// (j + rot) % 5; four outputs move rot on by 4), so the loop is unrolled over the ten states
+//   hs = 0..9:  generator hs & 1 (A, B, A, ...), rot = (5 - hs / 2) % 5  (0 0 4 4 3 3 2 2 1 1)
+// and entered at the body of the current state.  EXEC is all ones throughout (every lane's generator advances with
+// every draw); the lanes still iterating are scalar masks, and the iteration count of the reference is kept exact by
+// popcounts of those masks, as in draw_wave.hip's CB_STEP2.
+//
+// Draw of one output (xk: the oldest word, x0 of rocrand's step; xp: the newest, x4): the new word replaces xk;
+// out = d + k * 362437 + new word.
+#define CBW_D1(xk) "v_lshrrev_b32 %[t], 2, " xk "\n\t"
+#define CBW_D2(xp) "v_lshlrev_b32 %[u], 4, " xp "\n\t"
+#define CBW_DS(ck) "s_mov_b32 %[sc], " ck "\n\t"
+#define CBW_D3(xk) "v_xor_b32 %[t], %[t], " xk "\n\t"
+#define CBW_D4(xk) "v_lshlrev_b32 " xk ", 1, %[t]\n\t"
+#define CBW_D5(xp) "v_bitop3_b32 %[u], %[u], " xp ", %[t] bitop3:0x96\n\t"
+#define CBW_D6(xk) "v_xor_b32 " xk ", %[u], " xk "\n\t"
+#define CBW_D7(xk, xd, out) "v_add3_u32 " out ", " xd ", " xk ", %[sc]\n\t"
+static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u == 0x10974fu &&
+                  4u * 362437u == 0x161f14u,
+              "multiples of the Weyl increment (rocrand_xorwow.h:174)");
+// coordinate, up to the last operation: n = fma(hi, 2^32, lo) with lo = o1, hi = o2 >> 11 (0x41f00000: the high word
+// of 2^32 as the literal of a VOP2 fmac); the last operation C = fma(n, 2^-50, 2^-50 - 4) writes cr / ci behind the
+// test's last use of them
+#define CBW_C1(n) "v_cvt_f64_u32 " n ", %[o1]\n\t"
+#define CBW_C2 "v_lshrrev_b32 %[o2], 11, %[o2]\n\t"
+#define CBW_C3 "v_cvt_f64_u32 %[f], %[o2]\n\t"
+#define CBW_C4(n) "v_fmac_f64_e32 " n ", 0x41f00000, %[f]\n\t"
+
+// The test's instructions, in order (T..): EXEC full; m0 = lanes outside both regions (cudabrot.cu:398), m1 = lanes
+// still iterating; cnt = the iterations the reference executes for these samples in HEAD's four steps.
+// 0x3fd00000 / 0x40300000: the high words of 0.25 and 16.0 as VOPC literals.
+#ifdef CB_BURNING_SHIP
+// no shortcut in this variant (cudabrot.cu:397-399): II only, every lane goes on
+#define CBW_T2
+#define CBW_T3
+#define CBW_T4
+#define CBW_T5
+#define CBW_T6
+#define CBW_T7 "s_mov_b64 %[m0], -1\n\t"
+#define CBW_T8
+#define CBW_T9 "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
+#else
+#define CBW_T2 "v_add_f64 %[x], %[cr], -0.5\n\t"             /* X = 2 (re - 1/4) */
+#define CBW_T3 "v_add_f64 %[r], %[cr], 2.0\n\t"              /* T = 2 (re + 1) */
+#define CBW_T4 "v_fma_f64 %[q], %[x], %[x], %[a]\n\t"        /* Q */
+#define CBW_T5 "v_fma_f64 %[r], %[r], %[r], %[a]\n\t"        /* bulb: fma(T,T,II) */
+#define CBW_T6 "v_fma_f64 %[x], %[x], 2.0, %[q]\n\t"         /* S */
+#define CBW_T7 "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t" /* !(bulb < 1/4) */ \
+               "s_mov_b64 %[m0], vcc\n\t"
+#define CBW_T8 "v_mul_f64 %[q], %[q], %[x]\n\t"              /* Q * S */
+#define CBW_T9 "v_cmp_nlt_f64_e64 %[m1], %[q], %[a]\n\t"     /* !(Q*S < II) */ \
+               "s_and_b64 %[m0], %[m0], %[m1]\n\t"                               \
+               "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
+#endif
+#define CBW_T1 "v_mul_f64 %[a], %[ci], %[ci]\n\t"            /* II */
+// step 1 from z = c; its first product I*I is II
+#define CBW_S1A "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
+#define CBW_S1B "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
+#define CBW_SC "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+#define CBW_SD "v_mul_f64 %[a], %[r], %[r]\n\t"
+#define CBW_SE "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"
+#define CBW_SF "v_cmp_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
+#define CBW_S1G "s_and_b64 %[m1], %[m0], vcc\n\t"             /* still iterating after step 1 */
+// steps 2..4
+#define CBW_SN0 "s_bcnt1_i32_b64 %[tmp], %[m1]\n\t"
+#define CBW_SA "v_mul_f64 %[a], %[i], %[i]\n\t"
+#define CBW_SN1 "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"
+#define CBW_SB "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"
+#define CBW_SI "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"
+#define CBW_SG "s_and_b64 %[m1], %[m1], vcc\n\t"
+// survivors (m1) -> Q0: slot (tail + rank) & 127 of the ring at LDS byte address q0_lds (q0_ci 1024 bytes on)
+#define CBW_P0 "s_mov_b64 vcc, %[m1]\n\t"
+#define CBW_P1 "v_mbcnt_lo_u32_b32 %[slot], vcc_lo, 0\n\t"
+#define CBW_P2 "v_mbcnt_hi_u32_b32 %[slot], vcc_hi, %[slot]\n\t"
+#define CBW_P3 "v_add_u32 %[slot], %[tail], %[slot]\n\t"
+#define CBW_P4 "v_and_b32 %[slot], 0x7f, %[slot]\n\t"
+#define CBW_P5 "v_lshl_add_u32 %[slot], %[slot], 3, %[lds]\n\t"
+#define CBW_P6                                                     \
+  "s_mov_b64 exec, %[m1]\n\t"                                      \
+  "ds_write2st64_b64 %[slot], %[cr], %[ci] offset1:2\n\t"          \
+  "s_mov_b64 exec, -1\n\t"
+
+// One body: the test of the pending sample (cr, ci) interleaved with the draw of the next one from the generator
+// whose logical words x0..x4 are X0..X4 and whose Weyl value is XD.
+#define CBW_BODY(X0, X1, X2, X3, X4, XD)                                   \
+  CBW_T1 CBW_D1(X0) CBW_T2 CBW_D2(X4) CBW_DS("0x587c5")                    \
+  CBW_T3 CBW_D3(X0) CBW_T4 CBW_D4(X0) CBW_T5 CBW_D5(X4)                    \
+  CBW_T6 CBW_D6(X0) CBW_T7 CBW_D7(X0, XD, "%[o1]")                         \
+  CBW_T8 CBW_D1(X1) CBW_T9 CBW_D2(X0) CBW_DS("0xb0f8a")                    \
+  CBW_S1A CBW_D3(X1) CBW_S1B CBW_D4(X1) CBW_SC CBW_D5(X0)                  \
+  CBW_SD CBW_D6(X1) CBW_SE CBW_D7(X1, XD, "%[o2]")                         \
+  CBW_SF CBW_C1("%[nr]") CBW_S1G CBW_SN0                                   \
+  CBW_SA CBW_C2 CBW_SN1 CBW_SB CBW_C3 CBW_SI CBW_D1(X2)                    \
+  CBW_SC CBW_C4("%[nr]") CBW_SD CBW_D2(X1) CBW_DS("0x10974f")              \
+  CBW_SE CBW_D3(X2) CBW_SF CBW_D4(X2) CBW_SG CBW_SN0                       \
+  CBW_SA CBW_D5(X1) CBW_SN1 CBW_SB CBW_D6(X2) CBW_SI CBW_D7(X2, XD, "%[o1]") \
+  CBW_SC CBW_D1(X3) CBW_SD CBW_D2(X2) CBW_DS("0x161f14")                   \
+  CBW_SE CBW_D3(X3) CBW_SF CBW_D4(X3) CBW_SG CBW_SN0                       \
+  CBW_SA CBW_D5(X2) CBW_SN1 CBW_SB CBW_D6(X3) CBW_SI CBW_D7(X3, XD, "%[o2]") \
+  CBW_SC "v_add_u32 " XD ", %[sc], " XD "\n\t"                             \
+  CBW_SD CBW_C1("%[ni]") CBW_SE CBW_C2 CBW_SF CBW_C3                       \
+  CBW_SG CBW_P0 CBW_P1 CBW_C4("%[ni]") CBW_P2 CBW_P3 CBW_P4 CBW_P5 CBW_P6  \
+  "v_fma_f64 %[cr], %[nr], %[k2m50], %[kk]\n\t"                            \
+  "v_fma_f64 %[ci], %[ni], %[k2m50], %[kk]\n\t"
+
+// Behind a body: its statistics, the ring, the state, and whether the next body runs.  The statement ends behind the
+// body after which  the input has ended (halves == 0: the pending sample is the launch's last, the caller tests it),
+// or Q0 holds a MID pass (q0_count >= 64),  or the progress board is due (halves % 64 == 0).
+#define CBW_AFTER(next_hs, next_label)                               \
+  "s_bcnt1_i32_b64 %[tmp], %[m0]\n\t"                                \
+  "s_sub_u32 %[rej], %[rej], %[tmp]\n\t"  /* rejected: 64 - alive0 */ \
+  "s_add_u32 %[rej], %[rej], 64\n\t"                                 \
+  "s_add_u32 %[fast], %[fast], %[tmp]\n\t" /* escaped in HEAD: alive0 - alive4 */ \
+  "s_bcnt1_i32_b64 %[tmp], %[m1]\n\t"                                \
+  "s_sub_u32 %[fast], %[fast], %[tmp]\n\t"                           \
+  "s_add_u32 %[steps], %[steps], %[cnt]\n\t"                         \
+  "s_add_u32 %[q0c], %[q0c], %[tmp]\n\t"                             \
+  "s_add_u32 %[tail], %[tail], %[tmp]\n\t"                           \
+  "s_sub_u32 %[halves], %[halves], 1\n\t"                            \
+  "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
+  "s_cmp_eq_u32 %[halves], 0\n\t"                                    \
+  "s_cbranch_scc1 99f\n\t"                                           \
+  "s_cmp_ge_u32 %[q0c], 64\n\t"                                      \
+  "s_cbranch_scc1 99f\n\t"                                           \
+  "s_and_b32 %[tmp], %[halves], 63\n\t"                              \
+  "s_cmp_eq_u32 %[tmp], 0\n\t"                                       \
+  "s_cbranch_scc1 99f\n\t"                                           \
+  next_label
+
+#define CBW_GA(k) "%[a" #k "]"
+#define CBW_GB(k) "%[b" #k "]"
+// the ten bodies: generator A / B alternately, rot = 0 0 4 4 3 3 2 2 1 1 (logical word j in field (j + rot) % 5)
+#define CBW_BODY_A(f0, f1, f2, f3, f4) CBW_BODY("%[a" #f0 "]", "%[a" #f1 "]", "%[a" #f2 "]", "%[a" #f3 "]", "%[a" #f4 "]", "%[ad]")
+#define CBW_BODY_B(f0, f1, f2, f3, f4) CBW_BODY("%[b" #f0 "]", "%[b" #f1 "]", "%[b" #f2 "]", "%[b" #f3 "]", "%[b" #f4 "]", "%[bd]")
+
+struct Xorwow2 {
+  Xorwow a, b;
+};
+
+// Bodies in a row (at least one).  On entry a sample is pending in (cr, ci) and halves >= 1 draws are still to be
+// made; hs is the state (which generator the next draw takes, and its rotation).  q0_tail = q0_head + q0_count (only
+// its low seven bits matter).  The three statistics are added to.
+__device__ __forceinline__ void head_bodies(Xorwow2 &g, double &cr, double &ci, uint32_t &halves, uint32_t &hs,
+                                            uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
+                                            uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
+  static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CBW_P4 / CBW_P6");
+  unsigned long long save, m0, m1;
+  uint32_t cnt, tmp, sc, slot, t, u, o1, o2;
+  double a, r, i, x, q, f, nr, ni;
+  halves = __builtin_amdgcn_readfirstlane(halves);
+  hs = __builtin_amdgcn_readfirstlane(hs);
+  q0_tail = __builtin_amdgcn_readfirstlane(q0_tail);
+  q0_count = __builtin_amdgcn_readfirstlane(q0_count);
+  n_rejected = __builtin_amdgcn_readfirstlane(n_rejected);
+  n_too_fast = __builtin_amdgcn_readfirstlane(n_too_fast);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, -1\n\t"
+      // enter at the body of the current state
+      "s_cmp_ge_u32 %[hs], 5\n\t"
+      "s_cbranch_scc1 60f\n\t"
+      "s_cmp_eq_u32 %[hs], 0\n\t"
+      "s_cbranch_scc1 10f\n\t"
+      "s_cmp_eq_u32 %[hs], 1\n\t"
+      "s_cbranch_scc1 11f\n\t"
+      "s_cmp_eq_u32 %[hs], 2\n\t"
+      "s_cbranch_scc1 12f\n\t"
+      "s_cmp_eq_u32 %[hs], 3\n\t"
+      "s_cbranch_scc1 13f\n\t"
+      "s_branch 14f\n\t"
+      "60:\n\t"
+      "s_cmp_eq_u32 %[hs], 5\n\t"
+      "s_cbranch_scc1 15f\n\t"
+      "s_cmp_eq_u32 %[hs], 6\n\t"
+      "s_cbranch_scc1 16f\n\t"
+      "s_cmp_eq_u32 %[hs], 7\n\t"
+      "s_cbranch_scc1 17f\n\t"
+      "s_cmp_eq_u32 %[hs], 8\n\t"
+      "s_cbranch_scc1 18f\n\t"
+      "s_branch 19f\n\t"
+      "10:\n\t" CBW_BODY_A(0, 1, 2, 3, 4) CBW_AFTER("1", "11:\n\t")  // rot 0
+      CBW_BODY_B(0, 1, 2, 3, 4) CBW_AFTER("2", "12:\n\t")
+      CBW_BODY_A(4, 0, 1, 2, 3) CBW_AFTER("3", "13:\n\t")            // rot 4
+      CBW_BODY_B(4, 0, 1, 2, 3) CBW_AFTER("4", "14:\n\t")
+      CBW_BODY_A(3, 4, 0, 1, 2) CBW_AFTER("5", "15:\n\t")            // rot 3
+      CBW_BODY_B(3, 4, 0, 1, 2) CBW_AFTER("6", "16:\n\t")
+      CBW_BODY_A(2, 3, 4, 0, 1) CBW_AFTER("7", "17:\n\t")            // rot 2
+      CBW_BODY_B(2, 3, 4, 0, 1) CBW_AFTER("8", "18:\n\t")
+      CBW_BODY_A(1, 2, 3, 4, 0) CBW_AFTER("9", "19:\n\t")            // rot 1
+      CBW_BODY_B(1, 2, 3, 4, 0) CBW_AFTER("0", "s_branch 10b\n\t")
+      "99:\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [halves] "+s"(halves), [hs] "+s"(hs), [tail] "+s"(q0_tail), [q0c] "+s"(q0_count), [rej] "+s"(n_rejected),
+        [fast] "+s"(n_too_fast), [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
+        [save] "=&s"(save), [tmp] "=&s"(tmp), [sc] "=&s"(sc), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
+        [q] "=&v"(q), [slot] "=&v"(slot), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
+        [nr] "=&v"(nr), [ni] "=&v"(ni), [cr] "+v"(cr), [ci] "+v"(ci),
+        [a0] "+v"(g.a.x0), [a1] "+v"(g.a.x1), [a2] "+v"(g.a.x2), [a3] "+v"(g.a.x3), [a4] "+v"(g.a.x4), [ad] "+v"(g.a.d),
+        [b0] "+v"(g.b.x0), [b1] "+v"(g.b.x1), [b2] "+v"(g.b.x2), [b3] "+v"(g.b.x3), [b4] "+v"(g.b.x4), [bd] "+v"(g.b.d)
+      : [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50), [kk] "v"(0x1p-50 - 4.0)
+      : "vcc", "scc", "memory");
+}
+
+// logical word j of a generator whose words are rotated by ROT (field (j + ROT) % 5), and back
+template <int K>
+__device__ __forceinline__ uint32_t &xorwow_word(Xorwow &s) {
+  static_assert(K >= 0 && K < 5, "five words");
+  if constexpr (K == 0) return s.x0;
+  if constexpr (K == 1) return s.x1;
+  if constexpr (K == 2) return s.x2;
+  if constexpr (K == 3) return s.x3;
+  return s.x4;
+}
+template <int ROT>
+__device__ __forceinline__ Xorwow xorwow_unrotated(Xorwow &s) {  // rotated fields -> logical order
+  Xorwow r;
+  r.x0 = xorwow_word<(0 + ROT) % 5>(s);
+  r.x1 = xorwow_word<(1 + ROT) % 5>(s);
+  r.x2 = xorwow_word<(2 + ROT) % 5>(s);
+  r.x3 = xorwow_word<(3 + ROT) % 5>(s);
+  r.x4 = xorwow_word<(4 + ROT) % 5>(s);
+  r.d = s.d;
+  return r;
+}
+__device__ __forceinline__ Xorwow xorwow_unrotate(Xorwow s, uint32_t rot) {
+  switch (rot) {
+    case 1: return xorwow_unrotated<1>(s);
+    case 2: return xorwow_unrotated<2>(s);
+    case 3: return xorwow_unrotated<3>(s);
+    case 4: return xorwow_unrotated<4>(s);
+    default: return s;
+  }
+}
+// logical order -> fields rotated by 4 (what one sample drawn in logical order leaves for the bodies: hs = 1)
+__device__ __forceinline__ Xorwow xorwow_rotated4(const Xorwow &s) {
+  Xorwow r;  // logical j -> field (j + 4) % 5
+  r.x4 = s.x0;
+  r.x0 = s.x1;
+  r.x1 = s.x2;
+  r.x2 = s.x3;
+  r.x3 = s.x4;
+  r.d = s.d;
+  return r;
+}
+
+// ---- MID in one piece (draw_wave.hip, mid_pass): 64 lanes pop c from Q0, re-derive z after HEAD's four
+// iterations, run n_steps more under EXEC, push the survivors' (c, z) to Q1 ------------------------------------
+#define CB_STEP_LIT                                   \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
+#define CB_STEP_NOTEST                                \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+__device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_plus_head,
+                                         uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
+                                         uint32_t q1_lds, unsigned long long &alive,
+                                         uint32_t &lane_steps) {
+  static_assert(kQ0Cap == 128 && kQ1Cap == 96 && kHeadSteps == 4, "ring mask, ring length and plane distances below");
+  unsigned long long save;
+  uint32_t cnt, tmp, ctr, slot, wr;
+  double cr, ci, r, i, a;
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "v_and_b32 %[slot], 0x7f, %[lph]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q0]\n\t"
+      "ds_read_b64 %[cr], %[slot]\n\t"
+      "ds_read_b64 %[ci], %[slot] offset:1024\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      // HEAD's iterations again, from z = c (first product: I*I with I = ci)
+      "v_mul_f64 %[a], %[ci], %[ci]\n\t"
+      "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
+      "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
+      "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+      CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 2f\n\t"
+      "1:\n\t"
+      CB_STEP_LIT
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_mov_b64 %[alive], exec\n\t"
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
+      "v_add_u32 %[slot], %[tail], %[slot]\n\t"          // < 96 + 64
+      "v_subrev_u32 %[wr], 96, %[slot]\n\t"              // slot - 96: huge (unsigned) below 96
+      "v_min_u32 %[slot], %[slot], %[wr]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
+      "ds_write_b64 %[slot], %[cr]\n\t"
+      "ds_write_b64 %[slot], %[ci] offset:768\n\t"
+      "ds_write_b64 %[slot], %[r] offset:1536\n\t"
+      "ds_write_b64 %[slot], %[i] offset:2304\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [alive] "=&s"(alive), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr),
+        [slot] "=&v"(slot), [wr] "=&v"(wr), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r),
+        [i] "=&v"(i)
+      : [take] "s"(take), [lph] "v"(lane_plus_head), [q0] "s"(q0_lds), [n] "s"(n_steps),
+        [tail] "v"(q1_tail), [q1] "s"(q1_lds)
+      : "vcc", "scc", "memory");
+  lane_steps = cnt;
+}
+
+// ---- LONG: four orbits per lane, EXEC untouched, one escape test per chunk ------------------------------------
+//
+// draw_wave.hip's iterate_chunk2_sparse with four chains instead of two: every lane computes every step of its four
+// slots (an idle slot computes garbage that nothing reads), 16 fp64 instructions per step, and ONE test behind the
+// chunk's last step -- !(|Z|^2 <= 16), exact for every sample with |C|^2 below the threshold (escape is absorbing
+// there: DESIGN.md 4.1a), while the others (|c| within 2^-14 of 2: one sample in 10^8) are decided by recomputing the
+// orbit (verify_chunk_escape).
+#define CBW_L4A                                           \
+  "v_mul_f64 %[t0], %[i0], %[i0]\n\t"                     \
+  "v_mul_f64 %[t1], %[i1], %[i1]\n\t"                     \
+  "v_mul_f64 %[t2], %[i2], %[i2]\n\t"                     \
+  "v_mul_f64 %[t3], %[i3], %[i3]\n\t"                     \
+  "v_fma_f64 %[t0], %[r0], %[r0], -%[t0]\n\t"             \
+  "v_fma_f64 %[t1], %[r1], %[r1], -%[t1]\n\t"             \
+  "v_fma_f64 %[t2], %[r2], %[r2], -%[t2]\n\t"             \
+  "v_fma_f64 %[t3], %[r3], %[r3], -%[t3]\n\t"             \
+  "v_fma_f64 %[i0], " CB_AL "%[r0]" CB_AR ", " CB_AL "%[i0]" CB_AR ", %[ci0]\n\t" \
+  "v_fma_f64 %[i1], " CB_AL "%[r1]" CB_AR ", " CB_AL "%[i1]" CB_AR ", %[ci1]\n\t" \
+  "v_fma_f64 %[i2], " CB_AL "%[r2]" CB_AR ", " CB_AL "%[i2]" CB_AR ", %[ci2]\n\t" \
+  "v_fma_f64 %[i3], " CB_AL "%[r3]" CB_AR ", " CB_AL "%[i3]" CB_AR ", %[ci3]\n\t" \
+  "v_fma_f64 %[r0], %[t0], 0.5, %[cr0]\n\t"               \
+  "v_fma_f64 %[r1], %[t1], 0.5, %[cr1]\n\t"               \
+  "v_fma_f64 %[r2], %[t2], 0.5, %[cr2]\n\t"               \
+  "v_fma_f64 %[r3], %[t3], 0.5, %[cr3]\n\t"
+#define CBW_L4X5 CBW_L4A CBW_L4A CBW_L4A CBW_L4A CBW_L4A
+#define CBW_L4X30 CBW_L4X5 CBW_L4X5 CBW_L4X5 CBW_L4X5 CBW_L4X5 CBW_L4X5
+// behind the last step: d_k = escaped (!(|Z|^2 <= 16)), c_k = the sample is not of the sure class (!(|C|^2 < kt))
+#define CBW_L4TEST                                        \
+  "v_mul_f64 %[t0], %[r0], %[r0]\n\t"                     \
+  "v_mul_f64 %[t1], %[r1], %[r1]\n\t"                     \
+  "v_mul_f64 %[t2], %[r2], %[r2]\n\t"                     \
+  "v_mul_f64 %[t3], %[r3], %[r3]\n\t"                     \
+  "v_fma_f64 %[t0], %[i0], %[i0], %[t0]\n\t"              \
+  "v_fma_f64 %[t1], %[i1], %[i1], %[t1]\n\t"              \
+  "v_fma_f64 %[t2], %[i2], %[i2], %[t2]\n\t"              \
+  "v_fma_f64 %[t3], %[i3], %[i3], %[t3]\n\t"              \
+  "v_cmp_nle_f64_e64 %[d0], %[t0], %[k16]\n\t"            \
+  "v_cmp_nle_f64_e64 %[d1], %[t1], %[k16]\n\t"            \
+  "v_cmp_nle_f64_e64 %[d2], %[t2], %[k16]\n\t"            \
+  "v_cmp_nle_f64_e64 %[d3], %[t3], %[k16]\n\t"            \
+  "v_mul_f64 %[t0], %[cr0], %[cr0]\n\t"                   \
+  "v_mul_f64 %[t1], %[cr1], %[cr1]\n\t"                   \
+  "v_mul_f64 %[t2], %[cr2], %[cr2]\n\t"                   \
+  "v_mul_f64 %[t3], %[cr3], %[cr3]\n\t"                   \
+  "v_fma_f64 %[t0], %[ci0], %[ci0], %[t0]\n\t"            \
+  "v_fma_f64 %[t1], %[ci1], %[ci1], %[t1]\n\t"            \
+  "v_fma_f64 %[t2], %[ci2], %[ci2], %[t2]\n\t"            \
+  "v_fma_f64 %[t3], %[ci3], %[ci3], %[t3]\n\t"            \
+  "v_cmp_nlt_f64_e64 %[c0], %[t0], %[kt]\n\t"             \
+  "v_cmp_nlt_f64_e64 %[c1], %[t1], %[kt]\n\t"             \
+  "v_cmp_nlt_f64_e64 %[c2], %[t2], %[kt]\n\t"             \
+  "v_cmp_nlt_f64_e64 %[c3], %[t3], %[kt]\n\t"
+
+// kChunk steps on the four slots (called with EXEC = all 64 lanes).  esc[k]: lanes of mask[k] whose orbit escaped or
+// whose sample is not of the sure class; doubt: lanes (of any mask) that hold such a sample in some slot -- for
+// them the caller decides exactly (rare).  z of slots outside the masks is clobbered.
+__device__ __forceinline__ void iterate_chunk4(const unsigned long long (&mask)[kSlots], Orbit (&o)[kSlots],
+                                               unsigned long long (&esc)[kSlots], unsigned long long &doubt,
+                                               double threshold) {
+  static_assert(kChunk == 60 && kSlots == 4, "unrolled: 2 x 30 steps of four chains");
+  unsigned long long c0, c1, c2, c3, d0, d1, d2, d3;
+  double t0, t1, t2, t3;
+  const double k16 = 16.0, kt = threshold;
+  asm volatile(
+      CBW_L4X30 CBW_L4X30 CBW_L4TEST
+      "s_nop 2\n\t"
+      : [r0] "+v"(o[0].r), [i0] "+v"(o[0].i), [r1] "+v"(o[1].r), [i1] "+v"(o[1].i), [r2] "+v"(o[2].r),
+        [i2] "+v"(o[2].i), [r3] "+v"(o[3].r), [i3] "+v"(o[3].i), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+        [t3] "=&v"(t3), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [d0] "=&s"(d0),
+        [d1] "=&s"(d1), [d2] "=&s"(d2), [d3] "=&s"(d3)
+      : [cr0] "v"(o[0].cr), [ci0] "v"(o[0].ci), [cr1] "v"(o[1].cr), [ci1] "v"(o[1].ci), [cr2] "v"(o[2].cr),
+        [ci2] "v"(o[2].ci), [cr3] "v"(o[3].cr), [ci3] "v"(o[3].ci), [k16] "s"(k16), [kt] "s"(kt)
+      : "scc");
+  esc[0] = mask[0] & (d0 | c0);
+  esc[1] = mask[1] & (d1 | c1);
+  esc[2] = mask[2] & (d2 | c2);
+  esc[3] = mask[3] & (d3 | c3);
+  doubt = (mask[0] & c0) | (mask[1] & c1) | (mask[2] & c2) | (mask[3] & c3);
+}
+
+// The exact decision for the lanes of `doubt` (draw_wave.hip, verify_chunk_escape): did the orbit with starting
+// point (cr, ci) escape during the kChunk iterations after its first `done` ones?
+__device__ __forceinline__ unsigned long long verify_chunk_escape(unsigned long long doubt, const Orbit &o,
+                                                                  int done) {
+  bool escaped = false;
+  if (lane_in(doubt)) {
+    double r = o.cr, i = o.ci;
+    for (int k = 0; k < done; ++k) {
+#ifdef CB_BURNING_SHIP
+      (void) mandel_step2_ship(o.cr, o.ci, r, i);
+#else
+      (void) mandel_step2(o.cr, o.ci, r, i);
+#endif
+    }
+    for (int k = 0; k < kChunk && !escaped; ++k) {
+#ifdef CB_BURNING_SHIP
+      escaped = mandel_step2_ship(o.cr, o.ci, r, i) > 16.0;
+#else
+      escaped = mandel_step2(o.cr, o.ci, r, i) > 16.0;
+#endif
+    }
+  }
+  return __ballot(escaped);
+}
+
+#define CB_STR2(x) #x
+#define CB_STR(x) CB_STR2(x)
+#define CB_CHUNK_S CB_STR(CB_CHUNK)
+
+// long_refill (draw_wave.hip): the idle lanes (l_rem == 0) of the slot take (c, z) from Q1.
+__device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &seen_i, int &l_rem,
+                                            uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
+                                            uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
+                                            unsigned long long &full, unsigned long long &tail) {
+  static_assert(kQ1Cap == 96, "ring length and plane distances below");
+  unsigned long long save;
+  uint32_t n, rank, slot, t;
+  asm volatile(
+      "v_cmp_eq_u32_e32 vcc, 0, %[lrem]\n\t"            // idle lanes
+      "s_bcnt1_i32_b64 %[n], vcc\n\t"
+      "s_min_u32 %[n], %[n], %[qc]\n\t"
+      "s_cmp_eq_u32 %[n], 0\n\t"
+      "s_cbranch_scc1 1f\n\t"
+      "v_mbcnt_lo_u32_b32 %[rank], vcc_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[rank], vcc_hi, %[rank]\n\t"
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "v_cmpx_gt_u32_e32 vcc, %[n], %[rank]\n\t"         // the first n idle lanes
+      "v_add_u32 %[slot], %[head], %[rank]\n\t"          // < 96 + 64
+      "v_subrev_u32 %[t], 96, %[slot]\n\t"
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
+      "ds_read_b64 %[cr], %[slot]\n\t"
+      "ds_read_b64 %[ci], %[slot] offset:768\n\t"
+      "ds_read_b64 %[r], %[slot] offset:1536\n\t"
+      "ds_read_b64 %[i], %[slot] offset:2304\n\t"
+      "ds_read_b64 %[sr], %[slot] offset:1536\n\t"      // the saved point of the periodicity check = z
+      "ds_read_b64 %[si], %[slot] offset:2304\n\t"
+      "v_mov_b32 %[lrem], %[ls]\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "1:\n\t"
+      "v_cmp_le_u32_e32 vcc, " CB_CHUNK_S ", %[lrem]\n\t"
+      "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
+      "s_mov_b64 %[full], vcc\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
+        [lrem] "+v"(l_rem), [n] "=&s"(n), [full] "=&s"(full), [tail] "=&s"(tail), [save] "=&s"(save),
+        [rank] "=&v"(rank), [slot] "=&v"(slot), [t] "=&v"(t)
+      : [qc] "s"(q1_count), [head] "s"(q1_head), [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value)
+      : "vcc", "scc", "memory");
+  taken = n;
+}
+
+// long_retire (draw_wave.hip) with this kernel's Q2 ring (320 entries, q2_ci 2560 bytes on) and its iteration
+// bookkeeping: the lanes that push add what the stages have COUNTED for their orbit so far -- cntk - l_rem with
+// cntk = max_iter + kChunk: HEAD + MID + every LONG chunk incl. this one -- to `counted`.  The reference executes
+// k + 1 iterations for an orbit that escapes at index k, and exactly that many replay steps record it later
+// (cudabrot.cu:336,363); so over all pushed orbits  counted - replay steps  is what the sparse chunks counted beyond
+// the escapes, and the kernel reports iterate_steps - (counted - replay steps): exact without any lane ever knowing
+// the escape index of an orbit.
+#define CBW_RETIRE_ESCAPED                                 \
+      "s_mov_b64 %[save], exec\n\t"  \
+      "s_mov_b64 %[push], 0\n\t"  \
+      "s_mov_b64 %[ended], 0\n\t"  \
+      "s_mov_b64 %[per], 0\n\t"  \
+      "s_mov_b64 exec, %[esc]\n\t"  \
+      "s_cbranch_execz 1f\n\t"  \
+      "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem]\n\t"  \
+      "v_sub_u32 %[t], %[cntk], %[lrem]\n\t"  \
+      "v_mov_b32 %[lrem], 0\n\t"  \
+      "s_mov_b64 %[push], vcc\n\t"  \
+      "s_mov_b64 exec, vcc\n\t"  \
+      "s_cbranch_execz 1f\n\t"  \
+      "v_add_u32 %[acc], %[acc], %[t]\n\t"  \
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"  \
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"  \
+      "v_add_u32 %[slot], %[tail2], %[slot]\n\t"  \
+      "v_subrev_u32 %[t], 320, %[slot]\n\t"  \
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"  \
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"  \
+      "ds_write_b64 %[slot], %[cr]\n\t"  \
+      "ds_write_b64 %[slot], %[ci] offset:2560\n\t"  \
+      "1:\n\t"  \
+      "s_andn2_b64 exec, %[ran], %[esc]\n\t"  \
+      "s_cbranch_execz 3f\n\t"
+#define CBW_RETIRE_SURVIVORS                               \
+      "v_subrev_u32 %[lrem], " CB_CHUNK_S ", %[lrem]\n\t" \
+      "v_cmp_eq_u32_e64 %[ended], 0, %[lrem]\n\t"        \
+      "s_cmp_eq_u32 %[chkf], 0\n\t"                      \
+      "s_cbranch_scc1 2f\n\t"                            \
+      "v_cmp_eq_u64_e32 vcc, %[r], %[sr]\n\t"            \
+      "s_mov_b64 %[per], vcc\n\t"                        \
+      "v_cmp_eq_u64_e32 vcc, %[i], %[si]\n\t"            \
+      "s_and_b64 %[per], %[per], vcc\n\t"                \
+      "s_andn2_b64 %[per], %[per], %[ended]\n\t"         \
+      "s_cmp_eq_u64 %[per], 0\n\t"                       \
+      "s_cbranch_scc1 2f\n\t"                            \
+      "s_mov_b64 exec, %[per]\n\t"                       \
+      "v_add_co_u32 %[klo], vcc, %[klo], %[lrem]\n\t"    \
+      "s_nop 1\n\t"                                      \
+      "v_addc_co_u32 %[khi], vcc, 0, %[khi], vcc\n\t"    \
+      "v_mov_b32 %[lrem], 0\n\t"                         \
+      "s_andn2_b64 exec, %[ran], %[esc]\n\t"             \
+      "2:\n\t"                                           \
+      "s_andn2_b64 exec, exec, %[per]\n\t"
+#define CBW_RETIRE_TAIL                                    \
+      "v_sub_u32 %[t], %[ls], %[lrem]\n\t"               \
+      "v_cvt_f32_u32 %[t], %[t]\n\t"                     \
+      "v_mul_f32 %[t], %[invl], %[t]\n\t"                \
+      "v_rndne_f32 %[t], %[t]\n\t"                       \
+      "v_and_b32 %[t], %[kmask], %[t]\n\t"               \
+      "v_cmpx_eq_u32_e32 vcc, 0, %[t]\n\t"               \
+      "v_mov_b64 %[sr], %[r]\n\t"                        \
+      "v_mov_b64 %[si], %[i]\n\t"                        \
+      "3:\n\t"                                           \
+      "s_mov_b64 exec, %[save]\n\t"                      \
+      "s_nop 4\n\t"
+
+__device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, double &seen_i, int &l_rem,
+                                            uint32_t &skip_lo, uint32_t &skip_hi, uint32_t &counted,
+                                            unsigned long long ran, unsigned long long esc, int accept_rem,
+                                            uint32_t long_steps, uint32_t counted_base, uint32_t check_periodic,
+                                            uint32_t q2_tail, uint32_t q2_lds, unsigned long long &push,
+                                            unsigned long long &ended, unsigned long long &periodic) {
+  static_assert(kQ2Cap == 320, "ring length and plane distance above (q2_ci 2560 bytes on)");
+  unsigned long long save;
+  uint32_t slot, t;
+  const float inv_chunk = 1.0f / (float) kChunk;
+  const uint32_t low_mantissa = (1u << (24 - kBrentBits)) - 1u;
+  asm volatile(CBW_RETIRE_ESCAPED CBW_RETIRE_SURVIVORS CBW_RETIRE_TAIL
+               : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),
+                 [acc] "+v"(counted), [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic),
+                 [save] "=&s"(save), [slot] "=&v"(slot), [t] "=&v"(t)
+               : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),
+                 [cntk] "s"(counted_base), [chkf] "s"(check_periodic), [invl] "s"(inv_chunk), [kmask] "s"(low_mantissa),
+                 [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)
+               : "vcc", "scc", "memory");
+}
+
+// ---- REPLAY burst, software-pipelined: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream -------------
+//
+// A replaying lane holds z_n COMPUTED BUT NOT YET RECORDED (a fresh orbit: z_1, made when it is popped).  One
+// iteration of the loop, for the lanes of `act` (EXEC):
+//   record z_n     IncrementPixelCounter (cudabrot.cu:308-312): pixel of (R/2, I/2), the four bound tests as two
+//                  unsigned 64-bit compares of the quotients' bit patterns, the hits compacted with v_mbcnt and
+//                  stored side by side as row << 16 | col (draw_wave.hip, CB_REPLAY_*)
+//   leave if |z_n|^2 > 4   (cudabrot.cu:363) -- after recording the escaped point, like the reference
+//   z_{n+1} <- z_n^2 + c   (mandel_step2's six instructions, same order) and its |.|^2
+// and the instructions of "record z_n" alternate with those of "z_{n+1}": the two depend on z_n only.  A lane that
+// leaves has computed one point too many, which nothing reads.  17 vector instructions per step.
+#define CBW_REPLAY_BIN_POW2                               \
+  "v_fma_f64 %[fx], %[r], %[sx], %[ox]\n\t"               \
+  "v_fma_f64 %[fy], %[i], %[sy], %[oy]\n\t"
+#define CBW_DIV(q, num, den)                                        \
+  "v_div_scale_f64 %[d0], %[scp], " den ", " den ", " num "\n\t"    \
+  "v_rcp_f64 %[d2], %[d0]\n\t"                                      \
+  "v_div_scale_f64 %[d1], vcc, " num ", " den ", " num "\n\t"       \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_fma_f64 %[d3], -%[d0], %[d2], 1.0\n\t"                         \
+  "v_fma_f64 %[d2], %[d2], %[d3], %[d2]\n\t"                        \
+  "v_mul_f64 %[d3], %[d1], %[d2]\n\t"                               \
+  "v_fma_f64 %[d0], -%[d0], %[d3], %[d1]\n\t"                       \
+  "s_nop 1\n\t"                                                     \
+  "v_div_fmas_f64 %[d0], %[d0], %[d2], %[d3]\n\t"                   \
+  "v_div_fixup_f64 " q ", %[d0], " den ", " num "\n\t"
+// (draw_wave.hip, CB_REPLAY_BIN_DIV: the estimate RN(a * RN(1/d)) decides unless its fraction is within 2^-24 of
+// an integer; then the whole wave takes the IEEE division)
+#define CBW_REPLAY_BIN_DIV                                \
+  "v_fma_f64 %[fx], %[r], 0.5, -%[ox]\n\t"                \
+  "v_fma_f64 %[fy], %[i], 0.5, -%[oy]\n\t"                \
+  "v_mul_f64 %[d0], %[fx], %[rx]\n\t"                     \
+  "v_mul_f64 %[d1], %[fy], %[ry]\n\t"                     \
+  "v_fract_f64 %[d2], %[d0]\n\t"                          \
+  "v_fract_f64 %[d3], %[d1]\n\t"                          \
+  "v_add_f64 %[d2], %[d2], -0.5\n\t"                      \
+  "v_add_f64 %[d3], %[d3], -0.5\n\t"                      \
+  "v_cmp_nlt_f64_e64 %[scp], |%[d2]|, %[kg]\n\t"          \
+  "v_cmp_nlt_f64_e64 vcc, |%[d3]|, %[kg]\n\t"             \
+  "s_or_b64 %[scp], %[scp], vcc\n\t"                      \
+  "s_cbranch_scc0 4f\n\t"                                 \
+  CBW_DIV("%[fx]", "%[fx]", "%[sx]") CBW_DIV("%[fy]", "%[fy]", "%[sy]") \
+  "s_branch 5f\n\t"                                       \
+  "4:\n\t"                                                \
+  "v_mov_b64 %[fx], %[d0]\n\t"                            \
+  "v_mov_b64 %[fy], %[d1]\n\t"                            \
+  "5:\n\t"
+#define CBW_REPLAY_HEAD                                   \
+  "s_mov_b64 %[save], exec\n\t"                           \
+  "s_mov_b32 %[cs], 0\n\t"                                \
+  "s_mov_b32 %[ch], 0\n\t"                                \
+  "s_mov_b32 %[ctr], %[n]\n\t"                            \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"      /* |Z_n|^2 of the pending point, as the step that made it computed it */ \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "1:\n\t"                                                \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
+  "s_add_u32 %[clk], %[clk], 1\n\t"
+#define CBW_REPLAY_LOOP                                   \
+  "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t" \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
+  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "global_store_dword %[pidx], %[e], %[base]\n\t"         \
+  "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "s_cbranch_execz 2f\n\t"                                \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
+  "s_cbranch_scc1 1b\n\t"                                 \
+  "2:\n\t"                                                \
+  "s_mov_b64 exec, %[save]\n\t"                           \
+  "s_nop 4\n\t"
+
+// Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for 64 * n_steps more
+// entries.  On return `act` holds the lanes still replaying, `fill` the new fill, lane_steps / hits the executed
+// lane-steps and the entries appended, clock the wave's replay clock (one tick per step of a burst).
+template <bool kPow2>
+__device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p, uint32_t *region,
+                                             uint32_t &fill, uint32_t &clock, uint32_t &lane_steps, uint32_t &hits) {
+  unsigned long long save, alive, hx, scp;
+  uint32_t cs, ch, ctr, t;
+  double a, fx, fy, d0, d1, d2, d3;
+  uint32_t col, row, pidx, e;
+  const KernelArgs ka = fresh_args();
+  const double wb = (double) ka->w, hb = (double) ka->h;  // the bounds of the quotients, compared as bit patterns
+  region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
+  act = uniform_u64(act);
+  fill = __builtin_amdgcn_readfirstlane(fill);
+  clock = __builtin_amdgcn_readfirstlane(clock);
+  n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  const double k16 = 16.0;
+  const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
+  const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+  if (kPow2) {
+    asm volatile(CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [act] "+s"(act), [fill] "+s"(fill), [clk] "+s"(clock),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [cs] "=&s"(cs), [ch] "=&s"(ch),
+                   [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col),
+                   [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox),
+                   [oy] "v"(oy), [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16)
+                 : "vcc", "scc", "memory");
+  } else {
+    const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
+    const double kg = 0.5 - 0x1p-24;
+    asm volatile(CBW_REPLAY_HEAD CBW_REPLAY_BIN_DIV CBW_REPLAY_LOOP
+                 : [r] "+v"(p.r), [i] "+v"(p.i), [act] "+s"(act), [fill] "+s"(fill), [clk] "+s"(clock),
+                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [scp] "=&s"(scp), [cs] "=&s"(cs),
+                   [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy),
+                   [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col),
+                   [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e)
+                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox),
+                   [oy] "s"(oy), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg), [wb] "s"(wb), [hb] "s"(hb),
+                   [base] "s"(region), [k16] "s"(k16)
+                 : "vcc", "scc", "memory");
+  }
+  lane_steps = cs;
+  hits = ch;
+}
+
+__device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
+__device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
+
+__device__ __forceinline__ double step_of(double cr, double ci, double &r, double &i) {
+#ifdef CB_BURNING_SHIP
+  return mandel_step2_ship(cr, ci, r, i);
+#else
+  return mandel_step2(cr, ci, r, i);
+#endif
+}
+
+__global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // at most 128 vector registers: two of these waves and the
+draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 each) share a SIMD's 512
+  __shared__ WideQueues queues[kWavesPerBlock];
+  WideQueues &q = queues[threadIdx.x >> 6];
+
+  // this wave: subsequences [128 wave_id, 128 wave_id + 128): generator A of lane l is subsequence 128 wave_id + l,
+  // generator B 128 wave_id + 64 + l; stream segments 2 wave_id and 2 wave_id + 1 of the workspace (contiguous)
+  const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+  uint32_t *const region = a.bin.stream + (size_t) (2u * wave_id) * a.bin.cap;
+  const uint32_t region_cap = 2u * a.bin.cap;
+  uint32_t region_fill = 0;
+  const uint32_t tid_a = wave_id * 128u + (threadIdx.x & 63u), tid_b = tid_a + 64u;
+
+  const int max_iter = a.max_iter;
+  const int min_iter = a.min_iter;
+  const int long_start = a.head_steps + a.mid_steps;
+  const int tail_steps = (max_iter - long_start) % kChunk;
+
+  Xorwow2 rng;
+  rng.a = load_rng(a.states, a.n_threads, tid_a);
+  rng.b = load_rng(a.states, a.n_threads, tid_b);
+
+  // wave-uniform scheduler state and statistics (scalar registers)
+  uint32_t halves_left = 2u * a.samples_per_thread;  // draws still to make (A and B alternately)
+  uint32_t hs = 0;                                   // head_bodies' state
+  bool pending = false;                              // a drawn sample waits in (pend_cr, pend_ci) for its test
+  double pend_cr = 0.0, pend_ci = 0.0;
+  int q0_head = 0, q0_count = 0;
+  int q1_head = 0, q1_count = 0;
+  int q2_head = 0, q2_count = 0;
+  unsigned long long n_rejected = 0, n_never = 0, n_too_fast = 0, n_recorded = 0, n_iterate = 0,
+                     n_replay = 0, n_incr = 0, status = 0;
+  const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));  // HW_REG_HW_ID bits 3:0
+  uint32_t long_chunks = 0;
+  const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
+  const uint32_t q1_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q1_cr[0])));
+  const uint32_t q2_lds = __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q2_cr[0])));
+  // LONG lane state: four orbits per lane
+  Orbit lo[kSlots] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  double seen_r[kSlots] = {0, 0, 0, 0}, seen_i[kSlots] = {0, 0, 0, 0};  // periodicity check
+  int l_rem[kSlots] = {0, 0, 0, 0};   // iterations left before max_iter; 0 = idle
+  uint32_t skip_lo = 0, skip_hi = 0;  // per lane, 64 bits: iterations the periodicity check made unnecessary
+  uint32_t counted = 0;               // per lane: iterations counted for the orbits this lane pushed (long_retire)
+  // REPLAY lane state: z_n computed, not yet recorded
+  Orbit po = {0, 0, 0, 0};
+  bool p_act = false;
+  uint32_t p_start = 0;               // the wave's replay clock when this lane's orbit was popped
+  uint32_t replay_clock = 0;
+
+  // Carry-over: pick up the queues and orbit slots the previous launch left behind (DrawArgs::carry).
+  unsigned long long *const carry = a.carry + (size_t) wave_id * (2u * kCarryWordsPerWave);
+  // Progress board (kernels.h, kSchedWords; draw_wave.hip): the waves that share a SIMD post how many draws they
+  // still have to make and take s_setprio from their rank -- the one furthest behind issues first.
+  uint32_t *board_row;
+  {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID
+    const uint32_t key = ((xcc & 0xfu) << 12) | ((hw >> 4) & 0xfffu);                  // SIMD, pipe, CU, SH, SE
+    board_row = reinterpret_cast<uint32_t *>(a.carry + (size_t) gridDim.x * kWavesPerBlock * (2u * kCarryWordsPerWave)) +
+                (size_t) key * 16u;
+  }
+  auto post_progress_and_set_priority = [&](uint32_t still_to_draw) {
+    const uint32_t mine = still_to_draw + 1u;  // 0 = no wave in this slot
+    const uint32_t lane = (uint32_t) lane_id();
+    if (lane == 0u) {
+      __hip_atomic_store(board_row + (wave_slot & 15u), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t other = 0u;
+    if (lane < 16u) other = __hip_atomic_load(board_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool before_me = (lane < 16u) && (lane != (wave_slot & 15u)) &&
+                           (other > mine || (other == mine && lane < (wave_slot & 15u)));
+    const int rank = __popcll(__ballot(before_me));
+    // (the scatter's waves beside these run at priority 0: they issue little and wait for memory)
+    if (rank == 0) {
+      __builtin_amdgcn_s_setprio(3);
+    } else {
+      __builtin_amdgcn_s_setprio(2);
+    }
+  };
+  const uint32_t keep_rest = __builtin_amdgcn_readfirstlane(a.drain ? 1u : 0u);  // 0: leave in-flight work to the next launch
+  post_progress_and_set_priority(halves_left);
+  if (carry[0] == 2ull) {  // wave-uniform: the header is one address (2: a record of this kernel)
+    q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
+    q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));
+    q1_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[2]);
+    q1_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[2] >> 32));
+    q2_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[3]);
+    q2_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[3] >> 32));
+    replay_clock = __builtin_amdgcn_readfirstlane((uint32_t) carry[4]);
+    unsigned long long *lds_words = reinterpret_cast<unsigned long long *>(&q);
+    const unsigned long long *img = carry + kCarryHeaderWords;
+    for (uint32_t k = lane_id(); k < kWideQueueWords; k += 64u) lds_words[k] = img[k];
+    const unsigned long long *pl = img + kWideQueueWords + lane_id();
+#pragma unroll
+    for (int o = 0; o < kSlots; ++o) {
+      lo[o].cr = __longlong_as_double((long long) pl[(o * 6 + 0) * 64]);
+      lo[o].ci = __longlong_as_double((long long) pl[(o * 6 + 1) * 64]);
+      lo[o].r = __longlong_as_double((long long) pl[(o * 6 + 2) * 64]);
+      lo[o].i = __longlong_as_double((long long) pl[(o * 6 + 3) * 64]);
+      seen_r[o] = __longlong_as_double((long long) pl[(o * 6 + 4) * 64]);
+      seen_i[o] = __longlong_as_double((long long) pl[(o * 6 + 5) * 64]);
+    }
+    l_rem[0] = (int) (uint32_t) pl[24 * 64];
+    l_rem[1] = (int) (uint32_t) (pl[24 * 64] >> 32);
+    l_rem[2] = (int) (uint32_t) pl[25 * 64];
+    l_rem[3] = (int) (uint32_t) (pl[25 * 64] >> 32);
+    po.cr = __longlong_as_double((long long) pl[26 * 64]);
+    po.ci = __longlong_as_double((long long) pl[27 * 64]);
+    po.r = __longlong_as_double((long long) pl[28 * 64]);
+    po.i = __longlong_as_double((long long) pl[29 * 64]);
+    p_start = (uint32_t) pl[30 * 64];
+    p_act = (pl[30 * 64] >> 32) != 0ull;
+  }
+
+  for (;;) {
+    const bool input_done = (halves_left == 0) && !pending;
+    if (input_done && keep_rest == 0u) break;  // input done and the rest is left to the next launch
+    const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0 || l_rem[2] > 0 || l_rem[3] > 0) != 0ull;
+    const bool draining = input_done && (q0_count == 0) && (q1_count == 0) && !l_any;
+    const int n_replaying = __popcll(__ballot(p_act));
+
+    // ---------------------------------------------------------------- REPLAY
+    if ((q2_count > 0 && q2_count + n_replaying >= 64) || (draining && (q2_count > 0 || n_replaying > 0))) {
+      for (;;) {
+        {  // refill idle lanes from Q2: z_1 = c^2 + c is made here (it is the first point the reference records)
+          const unsigned long long idle_mask = __ballot(!p_act);
+          const int n_idle = __popcll(idle_mask);
+          const int n = n_idle < q2_count ? n_idle : q2_count;
+          if (n > 0) {
+            const int rank = mask_prefix(idle_mask);
+            if (!p_act && rank < n) {
+              const int slot = q2_wrap(q2_head + rank);
+              po.cr = q.q2_cr[slot];
+              po.ci = q.q2_ci[slot];
+              po.r = po.cr;
+              po.i = po.ci;
+              (void) step_of(po.cr, po.ci, po.r, po.i);
+              p_start = replay_clock;
+              p_act = true;
+            }
+            q2_head = q2_wrap(q2_head + n);
+            q2_count -= n;
+            n_recorded += (unsigned long long) n;
+          }
+        }
+        const int n_act = __popcll(__ballot(p_act));
+        if (n_act == 0) break;
+        if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
+
+        // The visited pixels go to this wave's stream region (compacted, coalesced stores) in a hand-written burst;
+        // a full region falls back to direct atomics below, so the result never depends on the workspace size.
+        if (region_fill + 64u * kReplayBurst <= region_cap) {
+          unsigned long long act_mask = __ballot(p_act);
+          uint32_t steps = 0, hits = 0;
+          const KernelArgs ra = fresh_args();
+          if (ra->pow2_real && ra->pow2_imag) {
+            replay_burst<true>(act_mask, kReplayBurst, po, region, region_fill, replay_clock, steps, hits);
+          } else {
+            replay_burst<false>(act_mask, kReplayBurst, po, region, region_fill, replay_clock, steps, hits);
+          }
+          n_replay += steps;
+          n_incr += hits;
+          p_act = lane_in(act_mask);
+          if (__ballot(p_act && (replay_clock - p_start) > (uint32_t) max_iter) != 0ull) {
+            // cannot happen: the orbit escaped within max_iter steps in an earlier stage
+            status |= CB_STATUS_REPLAY_RUNAWAY;
+            if ((replay_clock - p_start) > (uint32_t) max_iter) p_act = false;
+          }
+          continue;
+        }
+        const Canvas cv = make_canvas(a);
+        for (uint32_t b = 0; b < kReplayBurst; ++b) {
+          const unsigned long long act_mask = __ballot(p_act);
+          if (act_mask == 0ull) break;
+          replay_clock++;
+          n_replay += (unsigned long long) __popcll(act_mask);
+          bool done = false, hit = false;
+          if (p_act) {
+            int row = 0, col = 0;
+            hit = pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);  // cudabrot.cu:308-311 (halving is exact)
+            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);       // cudabrot.cu:312
+            done = __builtin_fma(po.i, po.i, po.r * po.r) > 16.0;    // cudabrot.cu:363, the value the step computed
+            if (!done && (replay_clock - p_start) > (uint32_t) max_iter) {
+              status |= CB_STATUS_REPLAY_RUNAWAY;
+              done = true;
+            }
+            if (done) {
+              p_act = false;
+            } else {
+              (void) step_of(po.cr, po.ci, po.r, po.i);              // cudabrot.cu:357-359
+            }
+          }
+          n_incr += (unsigned long long) __popcll(__ballot(hit));
+          if (__ballot(done) != 0ull && q2_count > 0) break;
+        }
+      }
+      if (draining) break;
+      continue;
+    }
+    if (draining) break;
+
+    // HEAD and MID feed the queues in a loop of their own (REPLAY > HEAD > MID > LONG, as in draw_wave.hip)
+    bool replay_ready = false;
+    uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
+    for (;;) {
+      if (q2_count > 0 && q2_count + n_replaying >= 64) {
+        replay_ready = true;
+        break;
+      }
+      const bool feed_input_done = (halves_left == 0) && !pending;
+      if (feed_input_done && keep_rest == 0u) break;  // the rest is left in the queues for the next launch
+      // ---------------------------------------------------------------- HEAD
+      if (!feed_input_done && q0_count < 64) {
+        if (!pending) {  // the launch's first sample: generator A, drawn in logical order, then rotated for the bodies
+          pend_cr = sample_coordinate2(rng.a);  // cudabrot.cu:392 (doubled, like everything below)
+          pend_ci = sample_coordinate2(rng.a);  // cudabrot.cu:393
+          rng.a = xorwow_rotated4(rng.a);
+          halves_left--;
+          hs = 1;
+          pending = true;
+          continue;
+        }
+        if (halves_left != 0) {
+          if ((halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
+          uint32_t count = (uint32_t) q0_count;
+          head_bodies(rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count, q0_lds,
+                      f_rejected, f_too_fast, f_steps);  // survivors -> Q0
+          q0_count = (int) count;
+          if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+          continue;
+        }
+        // the launch's last sample: its test alone (cudabrot.cu:398, 326-337)
+        {
+          Orbit o = {pend_cr, pend_ci, pend_cr, pend_ci};
+#ifdef CB_BURNING_SHIP
+          const bool alive = true;  // cudabrot.cu:397-399: no shortcut in this variant
+#else
+          const bool alive = !(in_main_cardioid2(o.cr, o.ci) || in_order2_bulb2(o.cr, o.ci));  // cudabrot.cu:398
+#endif
+          unsigned long long alive_mask = __ballot(alive);
+          f_rejected += 64u - (uint32_t) __popcll(alive_mask);
+          uint32_t steps = 0;
+          if (alive_mask != 0ull) {
+            const unsigned long long esc = iterate_steps(alive_mask, (uint32_t) kHeadSteps, o, steps);
+            f_steps += steps;
+            f_too_fast += (uint32_t) __popcll(esc);  // before min_iter (min_iter >= the start of the LONG stage)
+            alive_mask &= ~esc;
+          }
+          if (alive_mask != 0ull) {
+            if (lane_in(alive_mask)) {
+              const int slot = (q0_head + q0_count + mask_prefix(alive_mask)) & (kQ0Cap - 1);
+              q.q0_cr[slot] = o.cr;
+              q.q0_ci[slot] = o.ci;
+            }
+            q0_count += __popcll(alive_mask);
+            if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+          }
+          pending = false;
+        }
+        continue;
+      }
+
+      // ---------------------------------------------------------------- MID
+      if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
+        const int n = q0_count < 64 ? q0_count : 64;
+        const KernelArgs ma = fresh_args();
+        const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+        unsigned long long alive;
+        uint32_t steps;
+        mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
+                 (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
+        q0_head = (q0_head + n) & (kQ0Cap - 1);
+        q0_count -= n;
+        f_steps += steps;
+        f_too_fast += (uint32_t) __popcll(take & ~alive);  // escaped before min_iter
+        q1_count += __popcll(alive);
+        if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        continue;
+      }
+      break;
+    }  // feed loop
+    n_rejected += f_rejected;
+    n_too_fast += f_too_fast;
+    n_iterate += f_steps;
+    if (replay_ready) continue;
+    if ((halves_left == 0) && !pending && keep_rest == 0u) continue;  // leaves at the top: nothing drawn is lost
+
+    // ---------------------------------------------------------------- LONG
+    const KernelArgs la = fresh_args();
+    const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
+    const uint32_t check_flag = (uint32_t) la->check_periodic;
+    const int accept_rem = la->accept_rem;
+    const uint32_t counted_base = (uint32_t) la->max_iter + (uint32_t) kChunk;
+    uint32_t l_orbit_chunks = 0, l_never = 0;  // 32 bits inside the stage
+    for (;;) {
+      if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(halves_left);
+      ++long_chunks;
+      unsigned long long full_mask[kSlots], tail_mask[kSlots];
+#pragma unroll
+      for (int o = 0; o < kSlots; ++o) {  // refill idle orbit slots from Q1
+        uint32_t taken = 0;
+        long_refill(lo[o], seen_r[o], seen_i[o], l_rem[o], __builtin_amdgcn_readfirstlane((uint32_t) q1_head),
+                    __builtin_amdgcn_readfirstlane((uint32_t) q1_count), q1_lds, long_steps_u, tail_value, taken,
+                    full_mask[o], tail_mask[o]);
+        q1_head = q1_wrap(q1_head + (int) taken);
+        q1_count -= (int) taken;
+      }
+      const unsigned long long any_full = full_mask[0] | full_mask[1] | full_mask[2] | full_mask[3];
+      const unsigned long long any_tail = tail_mask[0] | tail_mask[1] | tail_mask[2] | tail_mask[3];
+      if ((any_full | any_tail) == 0ull) break;
+
+      if (any_tail != 0ull) {
+#pragma unroll
+        for (int o = 0; o < kSlots; ++o) {
+          if (tail_mask[o] != 0ull) {  // last, shorter chunk of these orbits: exactly tail_steps iterations
+            uint32_t steps = 0;
+            Orbit before = lo[o];
+            const unsigned long long esc_t = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o], steps);
+            n_iterate += steps;
+            n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc_t);  // reached max_iter (cudabrot.cu:339)
+            // every escape of the LONG stage is accepted (min_iter <= its start): all of esc_t go to Q2, and what
+            // was counted for each -- everything before this chunk plus its own steps in it, found again -- to `counted`
+            if (esc_t != 0ull) {
+              if (lane_in(esc_t)) {
+                uint32_t mine = 0;
+                bool out = false;
+                while (!out) {
+                  out = step_of(before.cr, before.ci, before.r, before.i) > 16.0;
+                  mine++;
+                }
+                counted += (uint32_t) (max_iter - l_rem[o]) + mine;
+                const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(esc_t));
+                q.q2_cr[slot] = lo[o].cr;
+                q.q2_ci[slot] = lo[o].ci;
+              }
+              q2_count += __popcll(esc_t);
+              if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+            }
+            if (lane_in(tail_mask[o])) l_rem[o] = 0;
+          }
+        }
+      }
+      if (any_full != 0ull) {
+        unsigned long long esc[kSlots], doubt;
+        iterate_chunk4(full_mask, lo, esc, doubt, la->sparse_threshold);
+        l_orbit_chunks += (uint32_t) (__popcll(full_mask[0]) + __popcll(full_mask[1]) + __popcll(full_mask[2]) +
+                                      __popcll(full_mask[3]));
+        if (doubt != 0ull) {  // a sample with |c| next to 2 somewhere in the wave: decided exactly, slot by slot
+          const double kt = la->sparse_threshold;
+#pragma unroll
+          for (int o = 0; o < kSlots; ++o) {
+            const bool unsure = !(__builtin_fma(lo[o].ci, lo[o].ci, lo[o].cr * lo[o].cr) < kt);
+            const unsigned long long d = __ballot(unsure) & full_mask[o];
+            if (d != 0ull) {
+              const unsigned long long really = verify_chunk_escape(d, lo[o], max_iter - l_rem[o]);
+              esc[o] = (esc[o] & ~d) | (really & d);
+            }
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < kSlots; ++o) {
+          unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
+          const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
+          long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, counted, uniform_u64(full_mask[o]),
+                      uniform_u64(esc[o]), accept_rem, long_steps_u, counted_base, check_flag, q2_tail, q2_lds, push,
+                      ended, periodic);
+          q2_count += __popcll(push);
+          if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+          if ((esc[o] & ~push) != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (cannot happen: every LONG escape is accepted)
+          l_never += (uint32_t) (__popcll(ended) + __popcll(periodic));
+        }
+      }
+      // leave the stage when another one has work to do
+      if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                              // REPLAY can fill every lane
+      if (q1_count < kQ1Exit && (halves_left != 0 || pending || q0_count > 0)) break;    // HEAD / MID must top up
+      if (l_orbit_chunks > (1u << 30)) break;                                             // (fold the 32-bit statistics)
+    }
+    n_iterate += (unsigned long long) kChunk * l_orbit_chunks;
+    n_never += l_never;
+  }
+
+  if (lane_id() == 0) {  // this wave no longer competes
+    __hip_atomic_store(board_row + (wave_slot & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // back to the logical order of the generator words: hs = 2 p + g -- A has drawn p + g samples (mod 5), B p
+  {
+    const uint32_t p = hs >> 1, g = hs & 1u;
+    rng.a = xorwow_unrotate(rng.a, (5u - (p + g) % 5u) % 5u);
+    rng.b = xorwow_unrotate(rng.b, (5u - p % 5u) % 5u);
+  }
+  store_rng(a.states, a.n_threads, tid_a, rng.a);
+  store_rng(a.states, a.n_threads, tid_b, rng.b);
+  if (lane_id() == 0) {  // the wave's segment as the two segments the scatter knows
+    a.bin.wave_count[2u * wave_id] = region_fill < a.bin.cap ? region_fill : a.bin.cap;
+    a.bin.wave_count[2u * wave_id + 1u] = region_fill < a.bin.cap ? 0u : region_fill - a.bin.cap;
+  }
+  {  // leave queues and orbit slots for the next launch (empty after a drain)
+    if (lane_id() == 0) {
+      carry[0] = 2ull;
+      carry[1] = (unsigned long long) (uint32_t) q0_head | ((unsigned long long) (uint32_t) q0_count << 32);
+      carry[2] = (unsigned long long) (uint32_t) q1_head | ((unsigned long long) (uint32_t) q1_count << 32);
+      carry[3] = (unsigned long long) (uint32_t) q2_head | ((unsigned long long) (uint32_t) q2_count << 32);
+      carry[4] = (unsigned long long) replay_clock;
+    }
+    const unsigned long long *lds_words = reinterpret_cast<const unsigned long long *>(&q);
+    unsigned long long *img = carry + kCarryHeaderWords;
+    for (uint32_t k = lane_id(); k < kWideQueueWords; k += 64u) img[k] = lds_words[k];
+    unsigned long long *pl = img + kWideQueueWords + lane_id();
+#pragma unroll
+    for (int o = 0; o < kSlots; ++o) {
+      pl[(o * 6 + 0) * 64] = (unsigned long long) __double_as_longlong(lo[o].cr);
+      pl[(o * 6 + 1) * 64] = (unsigned long long) __double_as_longlong(lo[o].ci);
+      pl[(o * 6 + 2) * 64] = (unsigned long long) __double_as_longlong(lo[o].r);
+      pl[(o * 6 + 3) * 64] = (unsigned long long) __double_as_longlong(lo[o].i);
+      pl[(o * 6 + 4) * 64] = (unsigned long long) __double_as_longlong(seen_r[o]);
+      pl[(o * 6 + 5) * 64] = (unsigned long long) __double_as_longlong(seen_i[o]);
+    }
+    pl[24 * 64] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
+    pl[25 * 64] = (unsigned long long) (uint32_t) l_rem[2] | ((unsigned long long) (uint32_t) l_rem[3] << 32);
+    pl[26 * 64] = (unsigned long long) __double_as_longlong(po.cr);
+    pl[27 * 64] = (unsigned long long) __double_as_longlong(po.ci);
+    pl[28 * 64] = (unsigned long long) __double_as_longlong(po.r);
+    pl[29 * 64] = (unsigned long long) __double_as_longlong(po.i);
+    pl[30 * 64] = (unsigned long long) p_start | ((unsigned long long) (p_act ? 1u : 0u) << 32);
+  }
+  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
+  const unsigned long long counted_total = wave_sum((unsigned long long) counted);
+  if (a.counters && lane_id() == 0) {
+    unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
+    const unsigned long long n_samples = 128ull * (unsigned long long) a.samples_per_thread;
+    // iterate_steps: what the stages counted, minus (counted for the pushed orbits - their replay steps): see
+    // long_retire.  Modulo 2^64 per launch (an orbit may be pushed in one launch and replayed in the next); exact
+    // once the carried work is complete, which is when anything reads the counters.
+    const unsigned long long v[9] = {n_samples, n_rejected, n_never,  n_too_fast, n_recorded,
+                                     n_iterate + skipped_total - counted_total + n_replay, n_replay, n_incr,
+                                     skipped_total};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (status) __hip_atomic_fetch_or(c + 9, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace
+
+#ifndef CB_BURNING_SHIP
+// Can this kernel take the launch?  (Everything else is draw_wave_kernel's.)
+bool draw_wide_takes(const DrawArgs &a) {
+  const bool binned_one_level = a.bin.enabled != 0u && a.bin.two_level == 0u && a.bin.chunked == 0u;
+  const bool usual_split = a.head_steps == kHeadSteps && a.fast_mid != 0 && a.sparse_long != 0 &&
+                           a.min_iter == a.long_start && a.max_iter > a.long_start;
+  return binned_one_level && usual_split && a.n_channels == 0 && a.carry != nullptr && a.n_threads != 0u &&
+         a.n_threads % (128u * kWavesPerBlock) == 0u && a.bin.n_waves == a.n_threads / 64u &&
+         a.bin.cap >= 64u * kReplayBurst;
+}
+#endif
+
+hipError_t CB_LAUNCH_NAME(const DrawArgs &a, hipStream_t stream) {
+  const bool drain_launch = a.drain != 0;
+  if (a.samples_per_thread == 0 && !drain_launch) return hipSuccess;
+  const uint32_t threads = 64 * kWavesPerBlock;
+  const uint32_t blocks = a.n_threads / (128u * kWavesPerBlock);
+  hipLaunchKernelGGL(draw_wide_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace cb
