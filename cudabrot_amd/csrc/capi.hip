@@ -386,12 +386,15 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
     if (rc) return rc;
   }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
+  // the two-waves-per-SIMD kernel where it applies (CUDABROT_AMD_NO_WIDE=1, a test knob: never)
+  const bool wide = cb::draw_wide_takes(a) && cb_debug_knob("CUDABROT_AMD_NO_WIDE") == nullptr;
+  const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
-      return (int) wave(a, false, s);
+      return (int) (wide ? wide_launch(a, s) : wave(a, false, s));
     case CB_KERNEL_FULL_ITERATE:
       a.check_periodic = 0;
-      return (int) wave(a, false, s);
+      return (int) (wide ? wide_launch(a, s) : wave(a, false, s));
     case CB_KERNEL_TIMED:
       if (cb_debug_knob("CUDABROT_AMD_TIMED_FULL")) a.check_periodic = 0;  // diagnostic: stage clocks of the full-iterate form
       return (int) wave(a, true, s);

@@ -883,7 +883,6 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   const uint32_t tid_a = wave_id * 128u + (threadIdx.x & 63u), tid_b = tid_a + 64u;
 
   const int max_iter = a.max_iter;
-  const int min_iter = a.min_iter;
   const int long_start = a.head_steps + a.mid_steps;
   const int tail_steps = (max_iter - long_start) % kChunk;
 

@@ -186,6 +186,13 @@ hipError_t launch_rng_init(uint64_t seed, uint64_t first_subsequence, uint32_t n
 hipError_t launch_draw_simple(const DrawArgs &a, hipStream_t stream);
 hipError_t launch_draw_wave(const DrawArgs &a, bool timed, hipStream_t stream);
 hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stream);
+// draw_wide.hip: the same path from two waves per SIMD (four orbits per lane in the LONG stage, software-pipelined
+// HEAD and REPLAY), so that the scatter of the previous launch fits beside it.  draw_wide_takes: the launches it
+// is built for (one-level workspace, one channel, the usual stage split, a carry buffer, whole workgroups of 512
+// subsequences); everything else is draw_wave_kernel's.  Same results, own carry format.
+bool draw_wide_takes(const DrawArgs &a);
+hipError_t launch_draw_wide(const DrawArgs &a, hipStream_t stream);
+hipError_t launch_draw_wide_ship(const DrawArgs &a, hipStream_t stream);
 
 // Steps per chunk of the LONG stage; the stage split is chosen so that no chunk straddles min_iter.
 // The exact-periodicity check compares z with a saved point at chunk boundaries only, so a cycle of period
