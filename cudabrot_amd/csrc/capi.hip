@@ -94,6 +94,8 @@ cb::DrawArgs make_args(const cb_fractal_dimensions *dims, const cb_iteration_con
   }
   a.w = dims->w;
   a.h = dims->h;
+  a.replay_bound_w = (double) dims->w;
+  a.replay_bound_h = (double) dims->h;
   a.max_iter = it->max_escape_iterations;
   a.min_iter = it->min_escape_iterations;
   cb::plan_stages(a.max_iter, a.min_iter, &a.head_steps, &a.mid_steps);

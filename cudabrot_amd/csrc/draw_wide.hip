@@ -303,13 +303,18 @@ struct Xorwow2 {
 // Bodies in a row (at least one).  On entry a sample is pending in (cr, ci) and halves >= 1 draws are still to be
 // made; hs is the state (which generator the next draw takes, and its rotation).  q0_tail = q0_head + q0_count (only
 // its low seven bits matter).  The three statistics are added to.
-__device__ __forceinline__ void head_bodies(Xorwow2 &g, double &cr, double &ci, uint32_t &halves, uint32_t &hs,
-                                            uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
+// Like every statement of this file that writes lane registers which live across the scheduler's loop, it is EXECUTED
+// in every iteration and skips its work when `enable` is 0: the loop body then is straight-line code for the
+// compiler, and every such register has one definition per iteration (as conditional blocks the statements made it
+// keep two copies of the whole lane state and move one into the other around every stage).
+__device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double &cr, double &ci, uint32_t &halves,
+                                            uint32_t &hs, uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
                                             uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
   static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CBW_P4 / CBW_P6");
   unsigned long long save, m0, m1;
   uint32_t cnt, tmp, sc, slot, t, u, o1, o2;
-  double a, r, i, x, q, f, nr, ni;
+  double a, r, i, x, q, f, nr, ni, kk;
+  enable = __builtin_amdgcn_readfirstlane(enable);
   halves = __builtin_amdgcn_readfirstlane(halves);
   hs = __builtin_amdgcn_readfirstlane(hs);
   q0_tail = __builtin_amdgcn_readfirstlane(q0_tail);
@@ -319,7 +324,10 @@ __device__ __forceinline__ void head_bodies(Xorwow2 &g, double &cr, double &ci, 
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
+      "s_cmp_eq_u32 %[en], 0\n\t"
+      "s_cbranch_scc1 99f\n\t"
       "s_mov_b64 exec, -1\n\t"
+      "v_fma_f64 %[kk], %[k2m50], 1.0, -4.0\n\t"  // 2^-50 - 4, exactly
       // enter at the body of the current state
       "s_cmp_ge_u32 %[hs], 5\n\t"
       "s_cbranch_scc1 60f\n\t"
@@ -359,10 +367,10 @@ __device__ __forceinline__ void head_bodies(Xorwow2 &g, double &cr, double &ci, 
         [fast] "+s"(n_too_fast), [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
         [save] "=&s"(save), [tmp] "=&s"(tmp), [sc] "=&s"(sc), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
         [q] "=&v"(q), [slot] "=&v"(slot), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
-        [nr] "=&v"(nr), [ni] "=&v"(ni), [cr] "+v"(cr), [ci] "+v"(ci),
+        [nr] "=&v"(nr), [ni] "=&v"(ni), [kk] "=&v"(kk), [cr] "+v"(cr), [ci] "+v"(ci),
         [a0] "+v"(g.a.x0), [a1] "+v"(g.a.x1), [a2] "+v"(g.a.x2), [a3] "+v"(g.a.x3), [a4] "+v"(g.a.x4), [ad] "+v"(g.a.d),
         [b0] "+v"(g.b.x0), [b1] "+v"(g.b.x1), [b2] "+v"(g.b.x2), [b3] "+v"(g.b.x3), [b4] "+v"(g.b.x4), [bd] "+v"(g.b.d)
-      : [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50), [kk] "v"(0x1p-50 - 4.0)
+      : [en] "s"(enable), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50)
       : "vcc", "scc", "memory");
 }
 
@@ -536,22 +544,34 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
 // kChunk steps on the four slots (called with EXEC = all 64 lanes).  esc[k]: lanes of mask[k] whose orbit escaped or
 // whose sample is not of the sure class; doubt: lanes (of any mask) that hold such a sample in some slot -- for
 // them the caller decides exactly (rare).  z of slots outside the masks is clobbered.
-__device__ __forceinline__ void iterate_chunk4(const unsigned long long (&mask)[kSlots], Orbit (&o)[kSlots],
-                                               unsigned long long (&esc)[kSlots], unsigned long long &doubt,
-                                               double threshold) {
+__device__ __forceinline__ void iterate_chunk4(uint32_t enable, const unsigned long long (&mask)[kSlots],
+                                               Orbit (&o)[kSlots], unsigned long long (&esc)[kSlots],
+                                               unsigned long long &doubt, double threshold) {
   static_assert(kChunk == 60 && kSlots == 4, "unrolled: 2 x 30 steps of four chains");
   unsigned long long c0, c1, c2, c3, d0, d1, d2, d3;
   double t0, t1, t2, t3;
   const double k16 = 16.0, kt = threshold;
+  enable = __builtin_amdgcn_readfirstlane(enable);
   asm volatile(
+      "s_mov_b64 %[c0], 0\n\t"
+      "s_mov_b64 %[c1], 0\n\t"
+      "s_mov_b64 %[c2], 0\n\t"
+      "s_mov_b64 %[c3], 0\n\t"
+      "s_mov_b64 %[d0], 0\n\t"
+      "s_mov_b64 %[d1], 0\n\t"
+      "s_mov_b64 %[d2], 0\n\t"
+      "s_mov_b64 %[d3], 0\n\t"
+      "s_cmp_eq_u32 %[en], 0\n\t"
+      "s_cbranch_scc1 9f\n\t"
       CBW_L4X30 CBW_L4X30 CBW_L4TEST
+      "9:\n\t"
       "s_nop 2\n\t"
       : [r0] "+v"(o[0].r), [i0] "+v"(o[0].i), [r1] "+v"(o[1].r), [i1] "+v"(o[1].i), [r2] "+v"(o[2].r),
         [i2] "+v"(o[2].i), [r3] "+v"(o[3].r), [i3] "+v"(o[3].i), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
         [t3] "=&v"(t3), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3), [d0] "=&s"(d0),
         [d1] "=&s"(d1), [d2] "=&s"(d2), [d3] "=&s"(d3)
       : [cr0] "v"(o[0].cr), [ci0] "v"(o[0].ci), [cr1] "v"(o[1].cr), [ci1] "v"(o[1].ci), [cr2] "v"(o[2].cr),
-        [ci2] "v"(o[2].ci), [cr3] "v"(o[3].cr), [ci3] "v"(o[3].ci), [k16] "s"(k16), [kt] "s"(kt)
+        [ci2] "v"(o[2].ci), [cr3] "v"(o[3].cr), [ci3] "v"(o[3].ci), [k16] "s"(k16), [kt] "s"(kt), [en] "s"(enable)
       : "scc");
   esc[0] = mask[0] & (d0 | c0);
   esc[1] = mask[1] & (d1 | c1);
@@ -590,14 +610,20 @@ __device__ __forceinline__ unsigned long long verify_chunk_escape(unsigned long 
 #define CB_CHUNK_S CB_STR(CB_CHUNK)
 
 // long_refill (draw_wave.hip): the idle lanes (l_rem == 0) of the slot take (c, z) from Q1.
-__device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &seen_i, int &l_rem,
+__device__ __forceinline__ void long_refill(uint32_t enable, Orbit &o, double &seen_r, double &seen_i, int &l_rem,
                                             uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
                                             uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
                                             unsigned long long &full, unsigned long long &tail) {
   static_assert(kQ1Cap == 96, "ring length and plane distances below");
   unsigned long long save;
   uint32_t n, rank, slot, t;
+  enable = __builtin_amdgcn_readfirstlane(enable);
   asm volatile(
+      "s_mov_b32 %[n], 0\n\t"
+      "s_mov_b64 %[full], 0\n\t"
+      "s_mov_b64 %[tail], 0\n\t"
+      "s_cmp_eq_u32 %[en], 0\n\t"
+      "s_cbranch_scc1 9f\n\t"
       "v_cmp_eq_u32_e32 vcc, 0, %[lrem]\n\t"            // idle lanes
       "s_bcnt1_i32_b64 %[n], vcc\n\t"
       "s_min_u32 %[n], %[n], %[qc]\n\t"
@@ -625,10 +651,12 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
       "s_mov_b64 %[full], vcc\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
+      "9:\n\t"
       : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
         [lrem] "+v"(l_rem), [n] "=&s"(n), [full] "=&s"(full), [tail] "=&s"(tail), [save] "=&s"(save),
         [rank] "=&v"(rank), [slot] "=&v"(slot), [t] "=&v"(t)
-      : [qc] "s"(q1_count), [head] "s"(q1_head), [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value)
+      : [qc] "s"(q1_count), [head] "s"(q1_head), [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value),
+        [en] "s"(enable)
       : "vcc", "scc", "memory");
   taken = n;
 }
@@ -645,6 +673,8 @@ __device__ __forceinline__ void long_refill(Orbit &o, double &seen_r, double &se
       "s_mov_b64 %[push], 0\n\t"  \
       "s_mov_b64 %[ended], 0\n\t"  \
       "s_mov_b64 %[per], 0\n\t"  \
+      "s_cmp_eq_u64 %[ran], 0\n\t"  /* nothing ran in this slot: nothing to retire */ \
+      "s_cbranch_scc1 3f\n\t"  \
       "s_mov_b64 exec, %[esc]\n\t"  \
       "s_cbranch_execz 1f\n\t"  \
       "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem]\n\t"  \
@@ -767,10 +797,51 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_mov_b64 %[fx], %[d0]\n\t"                            \
   "v_mov_b64 %[fy], %[d1]\n\t"                            \
   "5:\n\t"
-#define CBW_REPLAY_HEAD                                   \
+// The statement: refill, then the burst.
+//   refill   the idle lanes (not in `pact`) pop c from Q2 -- ring slot (q2_head + rank) mod 320 at LDS byte address
+//            q2_lds, q2_ci 2560 bytes on -- and make z_1 = c^2 + c (the first point the reference records,
+//            cudabrot.cu:357-360); their start time is the wave's replay clock
+//   burst    unless no lane replays, or fewer than kReplayMin do while Q2 is empty and the wave is not draining
+//            (then the replay waits, its state stays in registers)
+#define CBW_REPLAY_REFILL                                 \
   "s_mov_b64 %[save], exec\n\t"                           \
   "s_mov_b32 %[cs], 0\n\t"                                \
   "s_mov_b32 %[ch], 0\n\t"                                \
+  "s_mov_b32 %[nn], 0\n\t"                                \
+  "s_cmp_eq_u32 %[en], 0\n\t"                             \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_not_b64 vcc, %[act]\n\t"                             \
+  "s_bcnt1_i32_b64 %[nn], vcc\n\t"                        \
+  "s_min_u32 %[nn], %[nn], %[q2c]\n\t"                    \
+  "s_cmp_eq_u32 %[nn], 0\n\t"                             \
+  "s_cbranch_scc1 6f\n\t"                                 \
+  "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
+  "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "v_cmpx_gt_u32_e32 vcc, %[nn], %[pidx]\n\t"   /* the first nn idle lanes */ \
+  "v_add_u32 %[pidx], %[q2h], %[pidx]\n\t"      /* < 320 + 64 */ \
+  "v_subrev_u32 %[e], 320, %[pidx]\n\t"                   \
+  "v_min_u32 %[pidx], %[pidx], %[e]\n\t"                  \
+  "v_lshl_add_u32 %[pidx], %[pidx], 3, %[q2]\n\t"         \
+  "ds_read_b64 %[cr], %[pidx]\n\t"                        \
+  "ds_read_b64 %[ci], %[pidx] offset:2560\n\t"            \
+  "s_or_b64 %[act], %[act], exec\n\t"                     \
+  "v_mov_b32 %[pst], %[clk]\n\t"                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                              \
+  "v_mul_f64 %[a], %[ci], %[ci]\n\t"            /* z_1: mandel_step2 from z = c */ \
+  "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"               \
+  "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t" \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
+  "6:\n\t"                                                \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
+  "s_cmp_eq_u32 %[t], 0\n\t"                              \
+  "s_cbranch_scc1 2f\n\t"                                 \
+  "s_sub_u32 %[ctr], %[q2c], %[nn]\n\t"         /* fewer than minact lanes and Q2 empty: the replay waits */ \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                          \
+  "s_cselect_b32 %[ctr], 1, %[minact]\n\t"              \
+  "s_cmp_ge_u32 %[t], %[ctr]\n\t"                       \
+  "s_cbranch_scc0 2f\n\t"
+#define CBW_REPLAY_HEAD                                   \
   "s_mov_b32 %[ctr], %[n]\n\t"                            \
   "s_mov_b64 exec, %[act]\n\t"                            \
   "v_mul_f64 %[a], %[r], %[r]\n\t"      /* |Z_n|^2 of the pending point, as the step that made it computed it */ \
@@ -778,6 +849,8 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "1:\n\t"                                                \
   "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
   "s_add_u32 %[clk], %[clk], 1\n\t"
+// `direct` != 0 (the wave's stream region is full): the hits add to the histogram with device-scope atomics instead
+// (a one-level canvas has at most 2^24 pixels: the byte offset of a pixel fits 32 bits)
 #define CBW_REPLAY_LOOP                                   \
   "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
@@ -789,6 +862,8 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
+  "s_cmp_lg_u32 %[direct], 0\n\t"                         \
+  "s_cbranch_scc1 7f\n\t"                                 \
   "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
@@ -801,6 +876,19 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_mov_b64 exec, vcc\n\t"                               \
   "global_store_dword %[pidx], %[e], %[base]\n\t"         \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_branch 8f\n\t"                                       \
+  "7:\n\t"                                                \
+  "v_mad_u32_u24 %[pidx], %[row], %[wi], %[col]\n\t"      \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_lshlrev_b32 %[pidx], 3, %[pidx]\n\t"                 \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "v_mov_b64 %[fx], 1\n\t"             /* the 64-bit one (fx is free: its compares are done) */ \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "global_atomic_add_x2 %[pidx], %[fx], %[hist]\n\t"      \
+  "8:\n\t"                                                \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
   "s_mov_b64 exec, %[act]\n\t"                            \
   "s_cbranch_execz 2f\n\t"                                \
@@ -811,51 +899,122 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_mov_b64 exec, %[save]\n\t"                           \
   "s_nop 4\n\t"
 
-// Up to n_steps (>= 1) replay steps on the lanes of `act`; the stream region must have room for 64 * n_steps more
-// entries.  On return `act` holds the lanes still replaying, `fill` the new fill, lane_steps / hits the executed
-// lane-steps and the entries appended, clock the wave's replay clock (one tick per step of a burst).
+// The REPLAY stage's statement (see above; executed in every iteration of the scheduler, `enable` = 0 skips it).
+// act: the lanes with an orbit in flight; q2_head / q2_count: the ring; min_active: fewest lanes a burst is run
+// for; n_steps: steps of a burst (>= 1); the stream region must have room for 64 * n_steps more entries unless
+// `direct`.  Returns the orbits popped; lane_steps / hits: the executed lane-steps and the points recorded.
 template <bool kPow2>
-__device__ __forceinline__ void replay_burst(unsigned long long &act, uint32_t n_steps, Orbit &p, uint32_t *region,
-                                             uint32_t &fill, uint32_t &clock, uint32_t &lane_steps, uint32_t &hits) {
+__device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long long &act, uint32_t q2_head,
+                                                 uint32_t q2_count, uint32_t q2_lds, uint32_t min_active,
+                                                 uint32_t n_steps, uint32_t direct, Orbit &p, uint32_t &p_start,
+                                                 uint32_t *region, uint32_t &fill, uint32_t &clock,
+                                                 uint32_t &lane_steps, uint32_t &hits) {
+  static_assert(kQ2Cap == 320, "ring length and plane distance in CBW_REPLAY_REFILL");
   unsigned long long save, alive, hx, scp;
-  uint32_t cs, ch, ctr, t;
-  double a, fx, fy, d0, d1, d2, d3;
-  uint32_t col, row, pidx, e;
+  uint32_t cs, ch, ctr, t, nn;
+  double a, fx, fy, d0, d1, d2, d3, ox, oy;
+  uint32_t pidx, e, col, row;
   const KernelArgs ka = fresh_args();
-  const double wb = (double) ka->w, hb = (double) ka->h;  // the bounds of the quotients, compared as bit patterns
+  const double wb = ka->replay_bound_w, hb = ka->replay_bound_h;  // (double) w, h: the bounds of the quotients, compared as bit patterns
+  const uint32_t wi = (uint32_t) ka->w;
+  const unsigned long long hist = reinterpret_cast<unsigned long long>(ka->hist);
   region = reinterpret_cast<uint32_t *>(uniform_u64(reinterpret_cast<unsigned long long>(region)));
+  enable = __builtin_amdgcn_readfirstlane(enable);
   act = uniform_u64(act);
   fill = __builtin_amdgcn_readfirstlane(fill);
   clock = __builtin_amdgcn_readfirstlane(clock);
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  q2_head = __builtin_amdgcn_readfirstlane(q2_head);
+  q2_count = __builtin_amdgcn_readfirstlane(q2_count);
+  min_active = __builtin_amdgcn_readfirstlane(min_active);
+  direct = __builtin_amdgcn_readfirstlane(direct);
   const double k16 = 16.0;
   const double sx = ka->replay_scale_real, sy = ka->replay_scale_imag;
-  const double ox = ka->replay_offset_real, oy = ka->replay_offset_imag;
+  const double oxs = ka->replay_offset_real, oys = ka->replay_offset_imag;
+#define CBW_REPLAY_OUT                                                                                             \
+  [r] "+v"(p.r), [i] "+v"(p.i), [cr] "+v"(p.cr), [ci] "+v"(p.ci), [pst] "+v"(p_start), [act] "+s"(act),            \
+      [fill] "+s"(fill), [clk] "+s"(clock), [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx),              \
+      [cs] "=&s"(cs), [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [nn] "=&s"(nn), [a] "=&v"(a), [fx] "=&v"(fx), \
+      [fy] "=&v"(fy), [e] "=&v"(e), [col] "=&v"(col), [row] "=&v"(row), [pidx] "=&v"(pidx)
+#define CBW_REPLAY_IN                                                                                              \
+  [en] "s"(enable), [n] "s"(n_steps), [q2h] "s"(q2_head), [q2c] "s"(q2_count), [q2] "s"(q2_lds),                   \
+      [minact] "s"(min_active), [direct] "s"(direct), [sx] "s"(sx), [sy] "s"(sy), [wb] "s"(wb), [hb] "s"(hb),      \
+      [wi] "s"(wi), [hist] "s"(hist), [base] "s"(region), [k16] "s"(k16)
+  (void) ox;
+  (void) oy;
   if (kPow2) {
-    asm volatile(CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [act] "+s"(act), [fill] "+s"(fill), [clk] "+s"(clock),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [cs] "=&s"(cs), [ch] "=&s"(ch),
-                   [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy), [col] "=&v"(col),
-                   [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "v"(ox),
-                   [oy] "v"(oy), [wb] "s"(wb), [hb] "s"(hb), [base] "s"(region), [k16] "s"(k16)
+    asm volatile(CBW_REPLAY_REFILL
+                 "v_mov_b64 %[ox], %[oxs]\n\t"
+                 "v_mov_b64 %[oy], %[oys]\n\t"
+                 CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
+                 : CBW_REPLAY_OUT, [ox] "=&v"(ox), [oy] "=&v"(oy)
+                 : CBW_REPLAY_IN, [oxs] "s"(oxs), [oys] "s"(oys)
                  : "vcc", "scc", "memory");
   } else {
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
-    asm volatile(CBW_REPLAY_HEAD CBW_REPLAY_BIN_DIV CBW_REPLAY_LOOP
-                 : [r] "+v"(p.r), [i] "+v"(p.i), [act] "+s"(act), [fill] "+s"(fill), [clk] "+s"(clock),
-                   [save] "=&s"(save), [alive] "=&s"(alive), [hx] "=&s"(hx), [scp] "=&s"(scp), [cs] "=&s"(cs),
-                   [ch] "=&s"(ch), [ctr] "=&s"(ctr), [t] "=&s"(t), [a] "=&v"(a), [fx] "=&v"(fx), [fy] "=&v"(fy),
-                   [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [col] "=&v"(col),
-                   [row] "=&v"(row), [pidx] "=&v"(pidx), [e] "=&v"(e)
-                 : [n] "s"(n_steps), [cr] "v"(p.cr), [ci] "v"(p.ci), [sx] "s"(sx), [sy] "s"(sy), [ox] "s"(ox),
-                   [oy] "s"(oy), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg), [wb] "s"(wb), [hb] "s"(hb),
-                   [base] "s"(region), [k16] "s"(k16)
+    asm volatile(CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_DIV CBW_REPLAY_LOOP
+                 : CBW_REPLAY_OUT, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
+                 : CBW_REPLAY_IN, [ox] "s"(oxs), [oy] "s"(oys), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
                  : "vcc", "scc", "memory");
   }
+#undef CBW_REPLAY_OUT
+#undef CBW_REPLAY_IN
   lane_steps = cs;
   hits = ch;
+  return nn;
+}
+
+// The last, shorter chunk of the orbits of one slot (the lanes of `mask`; none: the statement does nothing): exactly
+// n_steps iterations with the reference's test after each (cudabrot.cu:326-337).  Every escape of the LONG stage is
+// accepted, so the escaped lanes push c to Q2 (ring slot (q2_tail + rank) mod 320 at q2_lds); all lanes of `mask`
+// end idle (l_rem = 0).  Returns the escaped lanes; lane_steps: the executed lane-steps.
+__device__ __forceinline__ unsigned long long long_tail(unsigned long long mask, uint32_t n_steps, Orbit &o, int &l_rem,
+                                                        uint32_t q2_tail, uint32_t q2_lds, uint32_t &lane_steps) {
+  unsigned long long save, escaped;
+  uint32_t cnt, tmp, ctr, slot, t;
+  double a;
+  const double k16 = 16.0;
+  mask = uniform_u64(mask);
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[cnt], 0\n\t"
+      "s_mov_b64 %[esc], 0\n\t"
+      "s_cmp_eq_u64 %[mask], 0\n\t"
+      "s_cbranch_scc1 9f\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      "s_mov_b32 %[ctr], %[n]\n\t"
+      "1:\n\t"
+      CB_STEP
+      "s_cbranch_execz 2f\n\t"
+      "s_sub_u32 %[ctr], %[ctr], 1\n\t"
+      "s_cmp_lg_u32 %[ctr], 0\n\t"
+      "s_cbranch_scc1 1b\n\t"
+      "2:\n\t"
+      "s_andn2_b64 %[esc], %[mask], exec\n\t"
+      "s_mov_b64 exec, %[esc]\n\t"
+      "s_cbranch_execz 3f\n\t"
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
+      "v_add_u32 %[slot], %[tail2], %[slot]\n\t"
+      "v_subrev_u32 %[t], 320, %[slot]\n\t"
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"
+      "ds_write_b64 %[slot], %[cr]\n\t"
+      "ds_write_b64 %[slot], %[ci] offset:2560\n\t"
+      "3:\n\t"
+      "s_mov_b64 exec, %[mask]\n\t"
+      "v_mov_b32 %[lrem], 0\n\t"
+      "9:\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [r] "+v"(o.r), [i] "+v"(o.i), [lrem] "+v"(l_rem), [a] "=&v"(a), [save] "=&s"(save), [esc] "=&s"(escaped),
+        [cnt] "=&s"(cnt), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr), [slot] "=&v"(slot), [t] "=&v"(t)
+      : [mask] "s"(mask), [n] "s"(n_steps), [cr] "v"(o.cr), [ci] "v"(o.ci), [k16] "s"(k16), [tail2] "s"(q2_tail),
+        [q2] "s"(q2_lds)
+      : "vcc", "scc", "memory");
+  lane_steps = cnt;
+  return escaped;
 }
 
 __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
@@ -869,6 +1028,10 @@ __device__ __forceinline__ double step_of(double cr, double ci, double &r, doubl
 #endif
 }
 
+// kPow2: both pixel sides are powers of two (the pixel of a point is one exact fma); else the guarded reciprocal with
+// the IEEE division behind it (CBW_REPLAY_BIN_DIV) -- an instance of its own, so that the division's temporaries do
+// not count against the other's registers.
+template <bool kPow2>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // at most 128 vector registers: two of these waves and the
 draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 each) share a SIMD's 512
   __shared__ WideQueues queues[kWavesPerBlock];
@@ -893,7 +1056,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t halves_left = 2u * a.samples_per_thread;  // draws still to make (A and B alternately)
   uint32_t hs = 0;                                   // head_bodies' state
-  bool pending = false;                              // a drawn sample waits in (pend_cr, pend_ci) for its test
+  uint32_t pending = 0;                              // 1: a drawn sample waits in (pend_cr, pend_ci) for its test
   double pend_cr = 0.0, pend_ci = 0.0;
   int q0_head = 0, q0_count = 0;
   int q1_head = 0, q1_count = 0;
@@ -916,9 +1079,10 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   uint32_t counted = 0;               // per lane: iterations counted for the orbits this lane pushed (long_retire)
   // REPLAY lane state: z_n computed, not yet recorded
   Orbit po = {0, 0, 0, 0};
-  bool p_act = false;
+  unsigned long long pact = 0ull;     // lanes with a replay in flight (wave-uniform mask)
   uint32_t p_start = 0;               // the wave's replay clock when this lane's orbit was popped
   uint32_t replay_clock = 0;
+  unsigned long long counted_s = 0;   // iterations counted for the orbits pushed by long_tail (see long_retire)
 
   // Carry-over: pick up the queues and orbit slots the previous launch left behind (DrawArgs::carry).
   unsigned long long *const carry = a.carry + (size_t) wave_id * (2u * kCarryWordsPerWave);
@@ -935,11 +1099,13 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   auto post_progress_and_set_priority = [&](uint32_t still_to_draw) {
     const uint32_t mine = still_to_draw + 1u;  // 0 = no wave in this slot
     const uint32_t lane = (uint32_t) lane_id();
+    uint32_t *row = board_row;
+    asm volatile("" : "+s"(row));  // (the lanes' addresses are formed here, not kept in registers across the launch)
     if (lane == 0u) {
-      __hip_atomic_store(board_row + (wave_slot & 15u), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(row + (wave_slot & 15u), mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     uint32_t other = 0u;
-    if (lane < 16u) other = __hip_atomic_load(board_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < 16u) other = __hip_atomic_load(row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool before_me = (lane < 16u) && (lane != (wave_slot & 15u)) &&
                            (other > mine || (other == mine && lane < (wave_slot & 15u)));
     const int rank = __popcll(__ballot(before_me));
@@ -982,274 +1148,184 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     po.r = __longlong_as_double((long long) pl[28 * 64]);
     po.i = __longlong_as_double((long long) pl[29 * 64]);
     p_start = (uint32_t) pl[30 * 64];
-    p_act = (pl[30 * 64] >> 32) != 0ull;
+    pact = __ballot((pl[30 * 64] >> 32) != 0ull);
   }
 
+  // The launch's first sample: generator A, drawn in logical order, its words then rotated the way the bodies expect
+  // them after one sample (outside the loop: the generator's registers are touched by head_bodies alone in there).
+  if (halves_left != 0u) {
+    pend_cr = sample_coordinate2(rng.a);  // cudabrot.cu:392 (doubled, like everything below)
+    pend_ci = sample_coordinate2(rng.a);  // cudabrot.cu:393
+    rng.a = xorwow_rotated4(rng.a);
+    halves_left--;
+    hs = 1;
+    pending = 1u;
+  }
+
+  // ONE stage action per iteration, in the order of precedence REPLAY > HEAD > MID > LONG.  The statements that write
+  // lane registers are executed in EVERY iteration and told by a scalar whether to do anything (head_bodies).
   for (;;) {
-    const bool input_done = (halves_left == 0) && !pending;
-    if (input_done && keep_rest == 0u) break;  // input done and the rest is left to the next launch
-    const bool l_any = __ballot(l_rem[0] > 0 || l_rem[1] > 0 || l_rem[2] > 0 || l_rem[3] > 0) != 0ull;
-    const bool draining = input_done && (q0_count == 0) && (q1_count == 0) && !l_any;
-    const int n_replaying = __popcll(__ballot(p_act));
+    const uint32_t input_left = halves_left | pending;
+    if ((input_left | keep_rest) == 0u) break;  // input done and the rest is left to the next launch
+    const int n_replaying = __popcll(pact);
+    bool draining = false;
+    if (input_left == 0u && q0_count == 0 && q1_count == 0) {
+      draining = __ballot(l_rem[0] > 0 || l_rem[1] > 0 || l_rem[2] > 0 || l_rem[3] > 0) == 0ull;
+    }
+    const bool do_replay = (q2_count > 0 && q2_count + n_replaying >= 64) || n_replaying >= kReplayMin ||
+                           (draining && (q2_count > 0 || n_replaying > 0));
+    if (draining && !do_replay) break;  // nothing is left at all
+    const bool do_head = !do_replay && input_left != 0u && q0_count < 64;
+    const bool do_mid = !do_replay && !do_head && q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || input_left == 0u);
+    const bool do_long = !do_replay && !do_head && !do_mid;
 
     // ---------------------------------------------------------------- REPLAY
-    if ((q2_count > 0 && q2_count + n_replaying >= 64) || (draining && (q2_count > 0 || n_replaying > 0))) {
-      for (;;) {
-        {  // refill idle lanes from Q2: z_1 = c^2 + c is made here (it is the first point the reference records)
-          const unsigned long long idle_mask = __ballot(!p_act);
-          const int n_idle = __popcll(idle_mask);
-          const int n = n_idle < q2_count ? n_idle : q2_count;
-          if (n > 0) {
-            const int rank = mask_prefix(idle_mask);
-            if (!p_act && rank < n) {
-              const int slot = q2_wrap(q2_head + rank);
-              po.cr = q.q2_cr[slot];
-              po.ci = q.q2_ci[slot];
-              po.r = po.cr;
-              po.i = po.ci;
-              (void) step_of(po.cr, po.ci, po.r, po.i);
-              p_start = replay_clock;
-              p_act = true;
-            }
-            q2_head = q2_wrap(q2_head + n);
-            q2_count -= n;
-            n_recorded += (unsigned long long) n;
-          }
-        }
-        const int n_act = __popcll(__ballot(p_act));
-        if (n_act == 0) break;
-        if (!draining && q2_count == 0 && n_act < kReplayMin) break;  // suspend
-
-        // The visited pixels go to this wave's stream region (compacted, coalesced stores) in a hand-written burst;
-        // a full region falls back to direct atomics below, so the result never depends on the workspace size.
-        if (region_fill + 64u * kReplayBurst <= region_cap) {
-          unsigned long long act_mask = __ballot(p_act);
-          uint32_t steps = 0, hits = 0;
-          const KernelArgs ra = fresh_args();
-          if (ra->pow2_real && ra->pow2_imag) {
-            replay_burst<true>(act_mask, kReplayBurst, po, region, region_fill, replay_clock, steps, hits);
-          } else {
-            replay_burst<false>(act_mask, kReplayBurst, po, region, region_fill, replay_clock, steps, hits);
-          }
-          n_replay += steps;
-          n_incr += hits;
-          p_act = lane_in(act_mask);
-          if (__ballot(p_act && (replay_clock - p_start) > (uint32_t) max_iter) != 0ull) {
-            // cannot happen: the orbit escaped within max_iter steps in an earlier stage
-            status |= CB_STATUS_REPLAY_RUNAWAY;
-            if ((replay_clock - p_start) > (uint32_t) max_iter) p_act = false;
-          }
-          continue;
-        }
-        const Canvas cv = make_canvas(a);
-        for (uint32_t b = 0; b < kReplayBurst; ++b) {
-          const unsigned long long act_mask = __ballot(p_act);
-          if (act_mask == 0ull) break;
-          replay_clock++;
-          n_replay += (unsigned long long) __popcll(act_mask);
-          bool done = false, hit = false;
-          if (p_act) {
-            int row = 0, col = 0;
-            hit = pixel_of(0.5 * po.r, 0.5 * po.i, cv, row, col);  // cudabrot.cu:308-311 (halving is exact)
-            if (hit) add_to_pixel(a.hist, cv, row, col, 1ull);       // cudabrot.cu:312
-            done = __builtin_fma(po.i, po.i, po.r * po.r) > 16.0;    // cudabrot.cu:363, the value the step computed
-            if (!done && (replay_clock - p_start) > (uint32_t) max_iter) {
-              status |= CB_STATUS_REPLAY_RUNAWAY;
-              done = true;
-            }
-            if (done) {
-              p_act = false;
-            } else {
-              (void) step_of(po.cr, po.ci, po.r, po.i);              // cudabrot.cu:357-359
-            }
-          }
-          n_incr += (unsigned long long) __popcll(__ballot(hit));
-          if (__ballot(done) != 0ull && q2_count > 0) break;
-        }
+    {
+      // The visited pixels go to this wave's stream region (compacted, coalesced stores); a full region makes the
+      // burst add to the histogram directly, so the result never depends on the workspace size.
+      const uint32_t direct = (region_fill + 64u * kReplayBurst <= region_cap) ? 0u : 1u;
+      uint32_t steps = 0, hits = 0, popped;
+      popped = replay_stage<kPow2>(do_replay ? 1u : 0u, pact, (uint32_t) q2_head, (uint32_t) q2_count, q2_lds,
+                                   draining ? 1u : (uint32_t) kReplayMin, kReplayBurst, direct, po, p_start, region,
+                                   region_fill, replay_clock, steps, hits);
+      q2_head = q2_wrap(q2_head + (int) popped);
+      q2_count -= (int) popped;
+      n_recorded += popped;
+      n_replay += steps;
+      n_incr += hits;
+      if (do_replay && __ballot(lane_in(pact) && (replay_clock - p_start) > (uint32_t) max_iter) != 0ull) {
+        // cannot happen: the orbit escaped within max_iter steps in an earlier stage
+        status |= CB_STATUS_REPLAY_RUNAWAY;
+        pact &= ~__ballot((replay_clock - p_start) > (uint32_t) max_iter);
       }
-      if (draining) break;
-      continue;
     }
-    if (draining) break;
 
-    // HEAD and MID feed the queues in a loop of their own (REPLAY > HEAD > MID > LONG, as in draw_wave.hip)
-    bool replay_ready = false;
-    uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
-    for (;;) {
-      if (q2_count > 0 && q2_count + n_replaying >= 64) {
-        replay_ready = true;
-        break;
-      }
-      const bool feed_input_done = (halves_left == 0) && !pending;
-      if (feed_input_done && keep_rest == 0u) break;  // the rest is left in the queues for the next launch
-      // ---------------------------------------------------------------- HEAD
-      if (!feed_input_done && q0_count < 64) {
-        if (!pending) {  // the launch's first sample: generator A, drawn in logical order, then rotated for the bodies
-          pend_cr = sample_coordinate2(rng.a);  // cudabrot.cu:392 (doubled, like everything below)
-          pend_ci = sample_coordinate2(rng.a);  // cudabrot.cu:393
-          rng.a = xorwow_rotated4(rng.a);
-          halves_left--;
-          hs = 1;
-          pending = true;
-          continue;
-        }
-        if (halves_left != 0) {
-          if ((halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
-          uint32_t count = (uint32_t) q0_count;
-          head_bodies(rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count, q0_lds,
-                      f_rejected, f_too_fast, f_steps);  // survivors -> Q0
-          q0_count = (int) count;
-          if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-          continue;
-        }
-        // the launch's last sample: its test alone (cudabrot.cu:398, 326-337)
-        {
-          Orbit o = {pend_cr, pend_ci, pend_cr, pend_ci};
+    // ---------------------------------------------------------------- HEAD
+    {
+      uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
+      const bool bodies = do_head && halves_left != 0u;
+      if (bodies && (halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
+      uint32_t count = (uint32_t) q0_count;
+      head_bodies(bodies ? 1u : 0u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
+                  q0_lds, f_rejected, f_too_fast, f_steps);  // survivors -> Q0
+      q0_count = (int) count;
+      if (do_head && !bodies) {  // the launch's last sample: its test alone (cudabrot.cu:398, 326-337)
+        Orbit o = {pend_cr, pend_ci, pend_cr, pend_ci};
 #ifdef CB_BURNING_SHIP
-          const bool alive = true;  // cudabrot.cu:397-399: no shortcut in this variant
+        const bool alive = true;  // cudabrot.cu:397-399: no shortcut in this variant
 #else
-          const bool alive = !(in_main_cardioid2(o.cr, o.ci) || in_order2_bulb2(o.cr, o.ci));  // cudabrot.cu:398
+        const bool alive = !(in_main_cardioid2(o.cr, o.ci) || in_order2_bulb2(o.cr, o.ci));  // cudabrot.cu:398
 #endif
-          unsigned long long alive_mask = __ballot(alive);
-          f_rejected += 64u - (uint32_t) __popcll(alive_mask);
-          uint32_t steps = 0;
-          if (alive_mask != 0ull) {
-            const unsigned long long esc = iterate_steps(alive_mask, (uint32_t) kHeadSteps, o, steps);
-            f_steps += steps;
-            f_too_fast += (uint32_t) __popcll(esc);  // before min_iter (min_iter >= the start of the LONG stage)
-            alive_mask &= ~esc;
-          }
-          if (alive_mask != 0ull) {
-            if (lane_in(alive_mask)) {
-              const int slot = (q0_head + q0_count + mask_prefix(alive_mask)) & (kQ0Cap - 1);
-              q.q0_cr[slot] = o.cr;
-              q.q0_ci[slot] = o.ci;
-            }
-            q0_count += __popcll(alive_mask);
-            if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-          }
-          pending = false;
+        unsigned long long alive_mask = __ballot(alive);
+        f_rejected = 64u - (uint32_t) __popcll(alive_mask);
+        if (alive_mask != 0ull) {
+          const unsigned long long esc = iterate_steps(alive_mask, (uint32_t) kHeadSteps, o, f_steps);
+          f_too_fast = (uint32_t) __popcll(esc);  // before min_iter (min_iter >= the start of the LONG stage)
+          alive_mask &= ~esc;
         }
-        continue;
+        if (alive_mask != 0ull) {
+          if (lane_in(alive_mask)) {
+            const int slot = (q0_head + q0_count + mask_prefix(alive_mask)) & (kQ0Cap - 1);
+            q.q0_cr[slot] = o.cr;
+            q.q0_ci[slot] = o.ci;
+          }
+          q0_count += __popcll(alive_mask);
+        }
+        pending = 0u;
       }
+      if (q0_count > kQ0Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+      n_rejected += f_rejected;
+      n_too_fast += f_too_fast;
+      n_iterate += f_steps;
+    }
 
-      // ---------------------------------------------------------------- MID
-      if (q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || feed_input_done)) {
-        const int n = q0_count < 64 ? q0_count : 64;
-        const KernelArgs ma = fresh_args();
-        const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-        unsigned long long alive;
-        uint32_t steps;
-        mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
-                 (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
-        q0_head = (q0_head + n) & (kQ0Cap - 1);
-        q0_count -= n;
-        f_steps += steps;
-        f_too_fast += (uint32_t) __popcll(take & ~alive);  // escaped before min_iter
-        q1_count += __popcll(alive);
-        if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-        continue;
+    // ---------------------------------------------------------------- MID (touches no lane register that lives on)
+    if (do_mid) {
+      const int n = q0_count < 64 ? q0_count : 64;
+      const KernelArgs ma = fresh_args();
+      const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+      unsigned long long alive;
+      uint32_t steps;
+      mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
+               (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
+      q0_head = (q0_head + n) & (kQ0Cap - 1);
+      q0_count -= n;
+      n_iterate += steps;
+      n_too_fast += (unsigned long long) __popcll(take & ~alive);  // escaped before min_iter
+      q1_count += __popcll(alive);
+      if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+    }
+
+    // ---------------------------------------------------------------- LONG: one chunk
+    {
+      const uint32_t en = do_long ? 1u : 0u;
+      const KernelArgs la = fresh_args();
+      const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
+      if (do_long) {
+        if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(halves_left);
+        ++long_chunks;
       }
-      break;
-    }  // feed loop
-    n_rejected += f_rejected;
-    n_too_fast += f_too_fast;
-    n_iterate += f_steps;
-    if (replay_ready) continue;
-    if ((halves_left == 0) && !pending && keep_rest == 0u) continue;  // leaves at the top: nothing drawn is lost
-
-    // ---------------------------------------------------------------- LONG
-    const KernelArgs la = fresh_args();
-    const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
-    const uint32_t check_flag = (uint32_t) la->check_periodic;
-    const int accept_rem = la->accept_rem;
-    const uint32_t counted_base = (uint32_t) la->max_iter + (uint32_t) kChunk;
-    uint32_t l_orbit_chunks = 0, l_never = 0;  // 32 bits inside the stage
-    for (;;) {
-      if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(halves_left);
-      ++long_chunks;
       unsigned long long full_mask[kSlots], tail_mask[kSlots];
 #pragma unroll
       for (int o = 0; o < kSlots; ++o) {  // refill idle orbit slots from Q1
         uint32_t taken = 0;
-        long_refill(lo[o], seen_r[o], seen_i[o], l_rem[o], __builtin_amdgcn_readfirstlane((uint32_t) q1_head),
+        long_refill(en, lo[o], seen_r[o], seen_i[o], l_rem[o], __builtin_amdgcn_readfirstlane((uint32_t) q1_head),
                     __builtin_amdgcn_readfirstlane((uint32_t) q1_count), q1_lds, long_steps_u, tail_value, taken,
                     full_mask[o], tail_mask[o]);
         q1_head = q1_wrap(q1_head + (int) taken);
         q1_count -= (int) taken;
       }
       const unsigned long long any_full = full_mask[0] | full_mask[1] | full_mask[2] | full_mask[3];
-      const unsigned long long any_tail = tail_mask[0] | tail_mask[1] | tail_mask[2] | tail_mask[3];
-      if ((any_full | any_tail) == 0ull) break;
-
-      if (any_tail != 0ull) {
 #pragma unroll
-        for (int o = 0; o < kSlots; ++o) {
-          if (tail_mask[o] != 0ull) {  // last, shorter chunk of these orbits: exactly tail_steps iterations
-            uint32_t steps = 0;
-            Orbit before = lo[o];
-            const unsigned long long esc_t = iterate_steps(tail_mask[o], (uint32_t) tail_steps, lo[o], steps);
-            n_iterate += steps;
-            n_never += (unsigned long long) __popcll(tail_mask[o] & ~esc_t);  // reached max_iter (cudabrot.cu:339)
-            // every escape of the LONG stage is accepted (min_iter <= its start): all of esc_t go to Q2, and what
-            // was counted for each -- everything before this chunk plus its own steps in it, found again -- to `counted`
-            if (esc_t != 0ull) {
-              if (lane_in(esc_t)) {
-                uint32_t mine = 0;
-                bool out = false;
-                while (!out) {
-                  out = step_of(before.cr, before.ci, before.r, before.i) > 16.0;
-                  mine++;
-                }
-                counted += (uint32_t) (max_iter - l_rem[o]) + mine;
-                const int slot = q2_wrap(q2_wrap(q2_head + q2_count) + mask_prefix(esc_t));
-                q.q2_cr[slot] = lo[o].cr;
-                q.q2_ci[slot] = lo[o].ci;
-              }
-              q2_count += __popcll(esc_t);
-              if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-            }
-            if (lane_in(tail_mask[o])) l_rem[o] = 0;
-          }
-        }
-      }
-      if (any_full != 0ull) {
-        unsigned long long esc[kSlots], doubt;
-        iterate_chunk4(full_mask, lo, esc, doubt, la->sparse_threshold);
-        l_orbit_chunks += (uint32_t) (__popcll(full_mask[0]) + __popcll(full_mask[1]) + __popcll(full_mask[2]) +
-                                      __popcll(full_mask[3]));
-        if (doubt != 0ull) {  // a sample with |c| next to 2 somewhere in the wave: decided exactly, slot by slot
-          const double kt = la->sparse_threshold;
-#pragma unroll
-          for (int o = 0; o < kSlots; ++o) {
-            const bool unsure = !(__builtin_fma(lo[o].ci, lo[o].ci, lo[o].cr * lo[o].cr) < kt);
-            const unsigned long long d = __ballot(unsure) & full_mask[o];
-            if (d != 0ull) {
-              const unsigned long long really = verify_chunk_escape(d, lo[o], max_iter - l_rem[o]);
-              esc[o] = (esc[o] & ~d) | (really & d);
-            }
-          }
-        }
-#pragma unroll
-        for (int o = 0; o < kSlots; ++o) {
-          unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
-          const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
-          long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, counted, uniform_u64(full_mask[o]),
-                      uniform_u64(esc[o]), accept_rem, long_steps_u, counted_base, check_flag, q2_tail, q2_lds, push,
-                      ended, periodic);
-          q2_count += __popcll(push);
+      for (int o = 0; o < kSlots; ++o) {  // the last, shorter chunk of an orbit (rare; the statement skips an empty mask)
+        uint32_t steps = 0;
+        const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
+        const unsigned long long esc_t = long_tail(tail_mask[o], (uint32_t) tail_steps, lo[o], l_rem[o], q2_tail, q2_lds, steps);
+        if (tail_mask[o] != 0ull) {
+          const uint32_t n_esc = (uint32_t) __popcll(esc_t), n_end = (uint32_t) __popcll(tail_mask[o] & ~esc_t);
+          n_iterate += steps;
+          n_never += n_end;  // reached max_iter (cudabrot.cu:339)
+          // what was counted for the pushed orbits: everything before this chunk and their own steps in it (the lanes
+          // that ended made tail_steps each)
+          counted_s += (unsigned long long) n_esc * (unsigned long long) (uint32_t) (max_iter - tail_steps) +
+                       (unsigned long long) (steps - n_end * (uint32_t) tail_steps);
+          q2_count += (int) n_esc;
           if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-          if ((esc[o] & ~push) != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (cannot happen: every LONG escape is accepted)
-          l_never += (uint32_t) (__popcll(ended) + __popcll(periodic));
         }
       }
-      // leave the stage when another one has work to do
-      if (q2_count + __popcll(__ballot(p_act)) >= 64) break;                              // REPLAY can fill every lane
-      if (q1_count < kQ1Exit && (halves_left != 0 || pending || q0_count > 0)) break;    // HEAD / MID must top up
-      if (l_orbit_chunks > (1u << 30)) break;                                             // (fold the 32-bit statistics)
+      unsigned long long esc[kSlots], doubt;
+      iterate_chunk4(any_full != 0ull ? 1u : 0u, full_mask, lo, esc, doubt, la->sparse_threshold);
+      n_iterate += (unsigned long long) kChunk * (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]) +
+                                                                       __popcll(full_mask[2]) + __popcll(full_mask[3]));
+      if (doubt != 0ull) {  // a sample with |c| next to 2 somewhere in the wave: decided exactly, slot by slot
+        const double kt = la->sparse_threshold;
+#pragma unroll
+        for (int o = 0; o < kSlots; ++o) {
+          const bool unsure = !(__builtin_fma(lo[o].ci, lo[o].ci, lo[o].cr * lo[o].cr) < kt);
+          const unsigned long long d = uniform_u64(__ballot(unsure)) & full_mask[o];
+          if (d != 0ull) {
+            const unsigned long long really = uniform_u64(verify_chunk_escape(d, lo[o], max_iter - l_rem[o]));
+            esc[o] = (esc[o] & ~d) | (really & d);
+          }
+          asm volatile("" ::: "memory");  // one slot after the other (a rare path: keep its registers few)
+        }
+      }
+      const uint32_t check_flag = (uint32_t) la->check_periodic;
+      const int accept_rem = la->accept_rem;
+      const uint32_t counted_base = (uint32_t) la->max_iter + (uint32_t) kChunk;
+#pragma unroll
+      for (int o = 0; o < kSlots; ++o) {
+        unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
+        const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
+        long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, counted, uniform_u64(full_mask[o]),
+                    uniform_u64(esc[o]), accept_rem, long_steps_u, counted_base, check_flag, q2_tail, q2_lds, push,
+                    ended, periodic);
+        q2_count += __popcll(push);
+        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+        if ((esc[o] & ~push) != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (cannot happen: every LONG escape is accepted)
+        n_never += (unsigned long long) (__popcll(ended) + __popcll(periodic));
+      }
     }
-    n_iterate += (unsigned long long) kChunk * l_orbit_chunks;
-    n_never += l_never;
   }
 
   if (lane_id() == 0) {  // this wave no longer competes
@@ -1261,13 +1337,25 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     rng.a = xorwow_unrotate(rng.a, (5u - (p + g) % 5u) % 5u);
     rng.b = xorwow_unrotate(rng.b, (5u - p % 5u) % 5u);
   }
-  store_rng(a.states, a.n_threads, tid_a, rng.a);
-  store_rng(a.states, a.n_threads, tid_b, rng.b);
+  // (the arguments read afresh and the pointers made opaque: addresses formed here, not kept in registers since the
+  // kernel began)
+  const KernelArgs ea = fresh_args();
+  {
+    uint32_t *const st = ea->states;
+    const uint32_t nt = ea->n_threads;
+    const uint32_t ta = __builtin_amdgcn_readfirstlane(wave_id) * 128u + (uint32_t) lane_id();
+    store_rng(st, nt, ta, rng.a);
+    store_rng(st, nt, ta + 64u, rng.b);
+  }
   if (lane_id() == 0) {  // the wave's segment as the two segments the scatter knows
-    a.bin.wave_count[2u * wave_id] = region_fill < a.bin.cap ? region_fill : a.bin.cap;
-    a.bin.wave_count[2u * wave_id + 1u] = region_fill < a.bin.cap ? 0u : region_fill - a.bin.cap;
+    uint32_t *const wc = ea->bin.wave_count;
+    const uint32_t cap = ea->bin.cap;
+    wc[2u * wave_id] = region_fill < cap ? region_fill : cap;
+    wc[2u * wave_id + 1u] = region_fill < cap ? 0u : region_fill - cap;
   }
   {  // leave queues and orbit slots for the next launch (empty after a drain)
+    unsigned long long *carry = ea->carry + (size_t) wave_id * (2u * kCarryWordsPerWave);
+    asm volatile("" : "+s"(carry));
     if (lane_id() == 0) {
       carry[0] = 2ull;
       carry[1] = (unsigned long long) (uint32_t) q0_head | ((unsigned long long) (uint32_t) q0_count << 32);
@@ -1294,13 +1382,13 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     pl[27 * 64] = (unsigned long long) __double_as_longlong(po.ci);
     pl[28 * 64] = (unsigned long long) __double_as_longlong(po.r);
     pl[29 * 64] = (unsigned long long) __double_as_longlong(po.i);
-    pl[30 * 64] = (unsigned long long) p_start | ((unsigned long long) (p_act ? 1u : 0u) << 32);
+    pl[30 * 64] = (unsigned long long) p_start | ((unsigned long long) (lane_in(pact) ? 1u : 0u) << 32);
   }
   const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
-  const unsigned long long counted_total = wave_sum((unsigned long long) counted);
-  if (a.counters && lane_id() == 0) {
-    unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
-    const unsigned long long n_samples = 128ull * (unsigned long long) a.samples_per_thread;
+  const unsigned long long counted_total = wave_sum((unsigned long long) counted) + counted_s;
+  if (ea->counters && lane_id() == 0) {
+    unsigned long long *c = reinterpret_cast<unsigned long long *>(ea->counters);
+    const unsigned long long n_samples = 128ull * (unsigned long long) ea->samples_per_thread;
     // iterate_steps: what the stages counted, minus (counted for the pushed orbits - their replay steps): see
     // long_retire.  Modulo 2^64 per launch (an orbit may be pushed in one launch and replayed in the next); exact
     // once the carried work is complete, which is when anything reads the counters.
@@ -1334,7 +1422,11 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, hipStream_t stream) {
   if (a.samples_per_thread == 0 && !drain_launch) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = a.n_threads / (128u * kWavesPerBlock);
-  hipLaunchKernelGGL(draw_wide_kernel, dim3(blocks), dim3(threads), 0, stream, a);
+  if (a.pow2_real && a.pow2_imag) {
+    hipLaunchKernelGGL(draw_wide_kernel<true>, dim3(blocks), dim3(threads), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(draw_wide_kernel<false>, dim3(blocks), dim3(threads), 0, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -115,6 +115,7 @@ struct DrawArgs {
   //   else:          scale = delta, offset = min                  (pixel = (R / 2 - offset) / scale)
   double replay_min2_real, replay_min2_imag;
   double replay_scale_real, replay_scale_imag, replay_offset_real, replay_offset_imag;
+  double replay_bound_w, replay_bound_h;  // (double) w, (double) h (draw_wide.hip)
   // Likewise the LONG stage's constants (from max_iter, min_iter and the stage split): iterations left to
   // the stage, the length of an orbit's last, shorter chunk and the l_rem that marks it (~0: none), and the
   // largest l_rem at which an escape is accepted (max_iter - min_iter)

@@ -130,3 +130,28 @@ for k in order:
         break
 k = order[0]
 print("live at the top point:", sorted(live_in[k]))
+
+# where is each register that is live at the top point used next?  (breadth-first over the successors)
+if len(sys.argv) > 4:
+    import collections
+    nxt = {}
+    for r in sorted(live_in[k]):
+        seen = {k}
+        dq = collections.deque([k])
+        while dq:
+            x = dq.popleft()
+            if r in insts[x][4]:
+                nxt[r] = x
+                break
+            if r in insts[x][3] and x != k:
+                continue
+            for y in succ[x]:
+                if y not in seen:
+                    seen.add(y)
+                    dq.append(y)
+    by_line = collections.defaultdict(list)
+    for r, x in nxt.items():
+        by_line[x].append(r)
+    for x in sorted(by_line):
+        ln, op, ops, d, u = insts[x]
+        print("  next use at line %d (%s %s): v%s" % (ln, op, ",".join(ops)[:50], by_line[x]))
