@@ -61,7 +61,6 @@ constexpr int kHeadSteps = 4;
 #define CB_WREPLAY_BURST 32
 #endif
 constexpr int kQ1Low = CB_WQ1_LOW;      // run MID while fewer deep orbits than this are queued
-constexpr int kQ1Exit = CB_WQ1_EXIT;    // LONG hands over to HEAD / MID below this many
 constexpr int kReplayMin = CB_WREPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = CB_WREPLAY_BURST;  // replay steps per asm burst
 constexpr uint32_t kBrentBits = 2;      // periodicity check: re-save when the chunk count has no bits below its top 2
@@ -327,7 +326,8 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
       "s_cmp_eq_u32 %[en], 0\n\t"
       "s_cbranch_scc1 99f\n\t"
       "s_mov_b64 exec, -1\n\t"
-      "v_fma_f64 %[kk], %[k2m50], 1.0, -4.0\n\t"  // 2^-50 - 4, exactly
+      "v_mov_b64 %[kk], %[k2m50]\n\t"
+      "v_add_f64 %[kk], %[kk], -4.0\n\t"  // 2^-50 - 4, exactly
       // enter at the body of the current state
       "s_cmp_ge_u32 %[hs], 5\n\t"
       "s_cbranch_scc1 60f\n\t"
@@ -975,7 +975,6 @@ __device__ __forceinline__ unsigned long long long_tail(unsigned long long mask,
   uint32_t cnt, tmp, ctr, slot, t;
   double a;
   const double k16 = 16.0;
-  mask = uniform_u64(mask);
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b32 %[cnt], 0\n\t"
@@ -1019,14 +1018,6 @@ __device__ __forceinline__ unsigned long long long_tail(unsigned long long mask,
 
 __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
-
-__device__ __forceinline__ double step_of(double cr, double ci, double &r, double &i) {
-#ifdef CB_BURNING_SHIP
-  return mandel_step2_ship(cr, ci, r, i);
-#else
-  return mandel_step2(cr, ci, r, i);
-#endif
-}
 
 // kPow2: both pixel sides are powers of two (the pixel of a point is one exact fma); else the guarded reciprocal with
 // the IEEE division behind it (CBW_REPLAY_BIN_DIV) -- an instance of its own, so that the division's temporaries do
@@ -1165,6 +1156,17 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   // ONE stage action per iteration, in the order of precedence REPLAY > HEAD > MID > LONG.  The statements that write
   // lane registers are executed in EVERY iteration and told by a scalar whether to do anything (head_bodies).
   for (;;) {
+    // the scheduler's state is wave-uniform by construction; readfirstlane makes that provable (scalar registers,
+    // scalar branches)
+    q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) q0_head);
+    q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) q0_count);
+    q1_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) q1_head);
+    q1_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) q1_count);
+    q2_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) q2_head);
+    q2_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) q2_count);
+    halves_left = __builtin_amdgcn_readfirstlane(halves_left);
+    pending = __builtin_amdgcn_readfirstlane(pending);
+    pact = uniform_u64(pact);
     const uint32_t input_left = halves_left | pending;
     if ((input_left | keep_rest) == 0u) break;  // input done and the rest is left to the next launch
     const int n_replaying = __popcll(pact);
@@ -1172,11 +1174,14 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     if (input_left == 0u && q0_count == 0 && q1_count == 0) {
       draining = __ballot(l_rem[0] > 0 || l_rem[1] > 0 || l_rem[2] > 0 || l_rem[3] > 0) == 0ull;
     }
-    const bool do_replay = (q2_count > 0 && q2_count + n_replaying >= 64) || n_replaying >= kReplayMin ||
-                           (draining && (q2_count > 0 || n_replaying > 0));
-    if (draining && !do_replay) break;  // nothing is left at all
-    const bool do_head = !do_replay && input_left != 0u && q0_count < 64;
-    const bool do_mid = !do_replay && !do_head && q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || input_left == 0u);
+    // (wave-uniform by construction; readfirstlane makes that provable, so that the stages' branches are scalar)
+    const auto uniform = [](bool c) { return __builtin_amdgcn_readfirstlane(c ? 1u : 0u) != 0u; };
+    const bool do_replay = uniform((q2_count > 0 && q2_count + n_replaying >= 64) || n_replaying >= kReplayMin ||
+                                   (draining && (q2_count > 0 || n_replaying > 0)));
+    if (uniform(draining) && !do_replay) break;  // nothing is left at all
+    const bool do_head = !do_replay && uniform(input_left != 0u && q0_count < 64);
+    const bool do_mid = !do_replay && !do_head &&
+                        uniform(q0_count > 0 && q1_count < kQ1Low && (q0_count >= 64 || input_left == 0u));
     const bool do_long = !do_replay && !do_head && !do_mid;
 
     // ---------------------------------------------------------------- REPLAY
@@ -1203,7 +1208,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     // ---------------------------------------------------------------- HEAD
     {
       uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
-      const bool bodies = do_head && halves_left != 0u;
+      const bool bodies = do_head && __builtin_amdgcn_readfirstlane(halves_left) != 0u;
       if (bodies && (halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
       uint32_t count = (uint32_t) q0_count;
       head_bodies(bodies ? 1u : 0u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
@@ -1241,9 +1246,9 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
 
     // ---------------------------------------------------------------- MID (touches no lane register that lives on)
     if (do_mid) {
-      const int n = q0_count < 64 ? q0_count : 64;
+      const int n = (int) __builtin_amdgcn_readfirstlane((uint32_t) (q0_count < 64 ? q0_count : 64));
       const KernelArgs ma = fresh_args();
-      const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+      const unsigned long long take = uniform_u64((n == 64) ? ~0ull : ((1ull << n) - 1ull));
       unsigned long long alive;
       uint32_t steps;
       mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
