@@ -943,10 +943,9 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
   (void) ox;
   (void) oy;
   if (kPow2) {
-    asm volatile(CBW_REPLAY_REFILL
-                 "v_mov_b64 %[ox], %[oxs]\n\t"
+    asm volatile("v_mov_b64 %[ox], %[oxs]\n\t"  // (in every lane: EXEC is all ones here, not behind the refill)
                  "v_mov_b64 %[oy], %[oys]\n\t"
-                 CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
+                 CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
                  : CBW_REPLAY_OUT, [ox] "=&v"(ox), [oy] "=&v"(oy)
                  : CBW_REPLAY_IN, [oxs] "s"(oxs), [oys] "s"(oys)
                  : "vcc", "scc", "memory");
