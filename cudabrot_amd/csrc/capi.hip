@@ -393,13 +393,13 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
-      return (int) (wide ? wide_launch(a, s) : wave(a, false, s));
+      return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));
     case CB_KERNEL_FULL_ITERATE:
       a.check_periodic = 0;
-      return (int) (wide ? wide_launch(a, s) : wave(a, false, s));
+      return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));
     case CB_KERNEL_TIMED:
       if (cb_debug_knob("CUDABROT_AMD_TIMED_FULL")) a.check_periodic = 0;  // diagnostic: stage clocks of the full-iterate form
-      return (int) wave(a, true, s);
+      return (int) (wide ? wide_launch(a, true, s) : wave(a, true, s));
     case CB_KERNEL_SIMPLE:
       return (int) cb::launch_draw_simple(a, s);
     default:

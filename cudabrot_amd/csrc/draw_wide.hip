@@ -1021,7 +1021,8 @@ __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot 
 // kPow2: both pixel sides are powers of two (the pixel of a point is one exact fma); else the guarded reciprocal with
 // the IEEE division behind it (CBW_REPLAY_BIN_DIV) -- an instance of its own, so that the division's temporaries do
 // not count against the other's registers.
-template <bool kPow2>
+// kTimed: stage clocks (s_memtime) into cb_counters, like draw_wave_kernel's timed variant (--kernel timed).
+template <bool kPow2, bool kTimed>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // at most 128 vector registers: two of these waves and the
 draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 each) share a SIMD's 512
   __shared__ WideQueues queues[kWavesPerBlock];
@@ -1055,6 +1056,9 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
                      n_replay = 0, n_incr = 0, status = 0;
   const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));  // HW_REG_HW_ID bits 3:0
   uint32_t long_chunks = 0;
+  unsigned long long t_head = 0, t_mid = 0, t_long = 0, t_replay = 0;
+  const unsigned long long t_start = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt_start = kTimed ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
       (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(&q.q0_cr[0])));
   const uint32_t q1_lds = __builtin_amdgcn_readfirstlane(
@@ -1184,7 +1188,8 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     const bool do_long = !do_replay && !do_head && !do_mid;
 
     // ---------------------------------------------------------------- REPLAY
-    {
+    const unsigned long long t0 = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
+    if (do_replay) {
       // The visited pixels go to this wave's stream region (compacted, coalesced stores); a full region makes the
       // burst add to the histogram directly, so the result never depends on the workspace size.
       const uint32_t direct = (region_fill + 64u * kReplayBurst <= region_cap) ? 0u : 1u;
@@ -1202,15 +1207,16 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
         status |= CB_STATUS_REPLAY_RUNAWAY;
         pact &= ~__ballot((replay_clock - p_start) > (uint32_t) max_iter);
       }
+      if (kTimed) t_replay += __builtin_amdgcn_s_memtime() - t0;
     }
 
     // ---------------------------------------------------------------- HEAD
-    {
+    if (do_head) {
       uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
       const bool bodies = do_head && __builtin_amdgcn_readfirstlane(halves_left) != 0u;
       if (bodies && (halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
       uint32_t count = (uint32_t) q0_count;
-      head_bodies(bodies ? 1u : 0u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
+      if (bodies) head_bodies(1u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
                   q0_lds, f_rejected, f_too_fast, f_steps);  // survivors -> Q0
       q0_count = (int) count;
       if (do_head && !bodies) {  // the launch's last sample: its test alone (cudabrot.cu:398, 326-337)
@@ -1241,6 +1247,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       n_rejected += f_rejected;
       n_too_fast += f_too_fast;
       n_iterate += f_steps;
+      if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
     }
 
     // ---------------------------------------------------------------- MID (touches no lane register that lives on)
@@ -1258,11 +1265,12 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       n_too_fast += (unsigned long long) __popcll(take & ~alive);  // escaped before min_iter
       q1_count += __popcll(alive);
       if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
+      if (kTimed) t_mid += __builtin_amdgcn_s_memtime() - t0;
     }
 
-    // ---------------------------------------------------------------- LONG: one chunk
-    {
-      const uint32_t en = do_long ? 1u : 0u;
+    // ---------------------------------------------------------------- LONG
+    if (do_long) {
+      const uint32_t en = 1u;
       const KernelArgs la = fresh_args();
       const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
       if (do_long) {
@@ -1329,6 +1337,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
         if ((esc[o] & ~push) != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (cannot happen: every LONG escape is accepted)
         n_never += (unsigned long long) (__popcll(ended) + __popcll(periodic));
       }
+      if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
     }
   }
 
@@ -1404,6 +1413,18 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       if (v[k]) __hip_atomic_fetch_add(c + k, v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (status) __hip_atomic_fetch_or(c + 9, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (kTimed) {  // cycles_head = HEAD + MID, as draw_wave_kernel reports them
+      const unsigned long long t_all = __builtin_amdgcn_s_memtime() - t_start;
+      __hip_atomic_fetch_add(c + 10, t_head + t_mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 11, t_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 12, t_replay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 13, t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+      __hip_atomic_fetch_max(c + 14, ~rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(c + 15, rt_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (the MID stage's share of cycles_head, in the slot draw_wave_kernel uses for the waves' lifetimes)
+      __hip_atomic_fetch_add(c + 16, t_mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1421,15 +1442,22 @@ bool draw_wide_takes(const DrawArgs &a) {
 }
 #endif
 
-hipError_t CB_LAUNCH_NAME(const DrawArgs &a, hipStream_t stream) {
+hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   const bool drain_launch = a.drain != 0;
   if (a.samples_per_thread == 0 && !drain_launch) return hipSuccess;
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = a.n_threads / (128u * kWavesPerBlock);
-  if (a.pow2_real && a.pow2_imag) {
-    hipLaunchKernelGGL(draw_wide_kernel<true>, dim3(blocks), dim3(threads), 0, stream, a);
+  const bool pow2 = a.pow2_real && a.pow2_imag;
+  if (timed) {
+    if (pow2) {
+      hipLaunchKernelGGL((draw_wide_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
+    } else {
+      hipLaunchKernelGGL((draw_wide_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
+    }
+  } else if (pow2) {
+    hipLaunchKernelGGL((draw_wide_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
   } else {
-    hipLaunchKernelGGL(draw_wide_kernel<false>, dim3(blocks), dim3(threads), 0, stream, a);
+    hipLaunchKernelGGL((draw_wide_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
   }
   return hipGetLastError();
 }

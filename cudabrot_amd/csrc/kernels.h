@@ -192,8 +192,8 @@ hipError_t launch_draw_wave_ship(const DrawArgs &a, bool timed, hipStream_t stre
 // is built for (one-level workspace, one channel, the usual stage split, a carry buffer, whole workgroups of 512
 // subsequences); everything else is draw_wave_kernel's.  Same results, own carry format.
 bool draw_wide_takes(const DrawArgs &a);
-hipError_t launch_draw_wide(const DrawArgs &a, hipStream_t stream);
-hipError_t launch_draw_wide_ship(const DrawArgs &a, hipStream_t stream);
+hipError_t launch_draw_wide(const DrawArgs &a, bool timed, hipStream_t stream);
+hipError_t launch_draw_wide_ship(const DrawArgs &a, bool timed, hipStream_t stream);
 
 // Steps per chunk of the LONG stage; the stage split is chosen so that no chunk straddles min_iter.
 // The exact-periodicity check compares z with a saved point at chunk boundaries only, so a cycle of period

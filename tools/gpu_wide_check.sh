@@ -27,4 +27,20 @@ except Exception as e:
     print(f, 'no line', e)
 PY
 done
+# stage clocks (sum over the waves, in shader cycles) of both kernels: --kernel timed
+for v in wide nowide; do
+  if [ $v = nowide ]; then export CUDABROT_AMD_NO_WIDE=1; else unset CUDABROT_AMD_NO_WIDE; fi
+  timeout -k 10 120 ./cudabrot --passes 256 -w 4096 -h 4096 -m 20000 --stats --kernel timed -o /dev/null > gpurun_out/timed_$v.log 2> gpurun_out/timed_$v.json
+  python3 - $v <<'PY'
+import json,sys
+v=sys.argv[1]
+try:
+    c=json.loads(open('gpurun_out/timed_%s.json'%v).read().strip().splitlines()[-1])
+    tot=c['cycles_total']
+    print(v,'cycles: head+mid %.3g (%.0f%%)  long %.3g (%.0f%%)  replay %.3g (%.0f%%)  total %.3g   mid-or-life %.3g   samples %.3g'%(c['cycles_head'],100*c['cycles_head']/tot,c['cycles_long'],100*c['cycles_long']/tot,c['cycles_replay'],100*c['cycles_replay']/tot,tot,c['rt_wave_life_sum'],c['samples']))
+except Exception as e:
+    print(v,'no stats',e)
+PY
+  grep "passes took" gpurun_out/timed_$v.log
+done
 echo SESSION DONE
