@@ -64,7 +64,8 @@ constexpr int kQ1Low = CB_WQ1_LOW;      // run MID while fewer deep orbits than 
 constexpr int kReplayMin = CB_WREPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = CB_WREPLAY_BURST;  // replay steps per asm burst
 constexpr uint32_t kBrentBits = 2;      // periodicity check: re-save when the chunk count has no bits below its top 2
-constexpr uint32_t kPrioChunks = 16;    // LONG chunks between two looks at the progress board (power of two)
+constexpr uint32_t kPrioChunks = 64;    // LONG chunks between two looks at the progress board (power of two)
+constexpr uint32_t kPrioHalves = 256;   // HEAD half-passes between two looks (power of two; a look costs a round trip to L2)
 
 // Ring capacities are exact worst cases (CB_STATUS_QUEUE_OVERFLOW guards the reasoning, these the constants):
 //   Q0: a HEAD half-pass runs while q0_count < 64 and pushes at most 64             -> 63 + 64
@@ -105,6 +106,9 @@ __device__ __forceinline__ KernelArgs fresh_args() {
   asm volatile("" : "+s"(p));
   return p;
 }
+// the same without the barrier: loads the compiler may hoist and keep in scalar registers (the stages of this kernel
+// run at two waves per SIMD, where a wait for a scalar load at every stage entry is not hidden by other waves)
+__device__ __forceinline__ KernelArgs kernel_args() { return (KernelArgs) __builtin_amdgcn_kernarg_segment_ptr(); }
 
 // ---- one orbit per lane under EXEC (MID, the last short chunk of LONG, the first and last HEAD sample) --------
 // (draw_wave.hip, CB_STEP: the six instructions of mandel_step2, the lane-step count, EXEC &= !(16 < |Z|^2))
@@ -267,7 +271,7 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 
 // Behind a body: its statistics, the ring, the state, and whether the next body runs.  The statement ends behind the
 // body after which  the input has ended (halves == 0: the pending sample is the launch's last, the caller tests it),
-// or Q0 holds a MID pass (q0_count >= 64),  or the progress board is due (halves % 64 == 0).
+// or Q0 holds a MID pass (q0_count >= 64),  or the progress board is due (halves % 256 == 0).
 #define CBW_AFTER(next_hs, next_label)                               \
   "s_bcnt1_i32_b64 %[tmp], %[m0]\n\t"                                \
   "s_sub_u32 %[rej], %[rej], %[tmp]\n\t"  /* rejected: 64 - alive0 */ \
@@ -284,7 +288,7 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
   "s_cbranch_scc1 99f\n\t"                                           \
   "s_cmp_ge_u32 %[q0c], 64\n\t"                                      \
   "s_cbranch_scc1 99f\n\t"                                           \
-  "s_and_b32 %[tmp], %[halves], 63\n\t"                              \
+  "s_and_b32 %[tmp], %[halves], 255\n\t"                             \
   "s_cmp_eq_u32 %[tmp], 0\n\t"                                       \
   "s_cbranch_scc1 99f\n\t"                                           \
   next_label
@@ -609,56 +613,70 @@ __device__ __forceinline__ unsigned long long verify_chunk_escape(unsigned long 
 #define CB_STR(x) CB_STR2(x)
 #define CB_CHUNK_S CB_STR(CB_CHUNK)
 
-// long_refill (draw_wave.hip): the idle lanes (l_rem == 0) of the slot take (c, z) from Q1.
-__device__ __forceinline__ void long_refill(uint32_t enable, Orbit &o, double &seen_r, double &seen_i, int &l_rem,
-                                            uint32_t q1_head, uint32_t q1_count, uint32_t q1_lds,
-                                            uint32_t long_steps, uint32_t tail_value, uint32_t &taken,
-                                            unsigned long long &full, unsigned long long &tail) {
-  static_assert(kQ1Cap == 96, "ring length and plane distances below");
+// long_refill4 (draw_wave.hip, long_refill, for the four slots in one statement): the idle lanes (l_rem == 0) of
+// every slot in turn take (c, z) from Q1 -- ring slot (q1_head + rank) mod 96 at LDS byte address q1_lds, planes 768
+// bytes apart -- with l_rem = long_steps and the periodicity check's saved point = the entry point; ONE wait for the
+// LDS behind all of them (at two waves per SIMD a wait per slot is not hidden by other waves).  full[k]: lanes of
+// slot k with a whole chunk ahead; tail[k]: lanes left with exactly the last, shorter chunk (l_rem == tail_value;
+// ~0 when there is none).  q1_head / q1_count are moved on.
+#define CBW_REFILL_SLOT(k)                                                \
+      "v_cmp_eq_u32_e32 vcc, 0, %[lrem" #k "]\n\t"     /* idle lanes */  \
+      "s_bcnt1_i32_b64 %[n], vcc\n\t"                                     \
+      "s_min_u32 %[n], %[n], %[qc]\n\t"                                   \
+      "s_cmp_eq_u32 %[n], 0\n\t"                                          \
+      "s_cbranch_scc1 2" #k "f\n\t"                                       \
+      "v_mbcnt_lo_u32_b32 %[rank], vcc_lo, 0\n\t"                         \
+      "v_mbcnt_hi_u32_b32 %[rank], vcc_hi, %[rank]\n\t"                   \
+      "s_mov_b64 exec, vcc\n\t"                                           \
+      "v_cmpx_gt_u32_e32 vcc, %[n], %[rank]\n\t"       /* the first n idle lanes */ \
+      "v_add_u32 %[slot], %[head], %[rank]\n\t"        /* < 96 + 64 */   \
+      "v_subrev_u32 %[t], 96, %[slot]\n\t"                                \
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"                              \
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"                     \
+      "ds_read_b64 %[cr" #k "], %[slot]\n\t"                              \
+      "ds_read_b64 %[ci" #k "], %[slot] offset:768\n\t"                   \
+      "ds_read_b64 %[r" #k "], %[slot] offset:1536\n\t"                   \
+      "ds_read_b64 %[i" #k "], %[slot] offset:2304\n\t"                   \
+      "ds_read_b64 %[sr" #k "], %[slot] offset:1536\n\t" /* the saved point of the periodicity check = z */ \
+      "ds_read_b64 %[si" #k "], %[slot] offset:2304\n\t"                  \
+      "v_mov_b32 %[lrem" #k "], %[ls]\n\t"                                \
+      "s_mov_b64 exec, %[save]\n\t"                                       \
+      "s_add_u32 %[head], %[head], %[n]\n\t"                              \
+      "s_sub_u32 %[qc], %[qc], %[n]\n\t"                                  \
+      "s_sub_u32 %[n], %[head], 96\n\t"                                   \
+      "s_cmp_ge_u32 %[head], 96\n\t"                                      \
+      "s_cselect_b32 %[head], %[n], %[head]\n\t"                          \
+      "2" #k ":\n\t"                                                      \
+      "v_cmp_le_u32_e32 vcc, " CB_CHUNK_S ", %[lrem" #k "]\n\t"           \
+      "v_cmp_eq_u32_e64 %[tail" #k "], %[tv], %[lrem" #k "]\n\t"          \
+      "s_mov_b64 %[full" #k "], vcc\n\t"
+__device__ __forceinline__ void long_refill4(Orbit (&o)[kSlots], double (&seen_r)[kSlots], double (&seen_i)[kSlots],
+                                             int (&l_rem)[kSlots], uint32_t &q1_head, uint32_t &q1_count, uint32_t q1_lds,
+                                             uint32_t long_steps, uint32_t tail_value,
+                                             unsigned long long (&full)[kSlots], unsigned long long (&tail)[kSlots]) {
+  static_assert(kQ1Cap == 96 && kSlots == 4, "ring length, plane distances and the four slot blocks below");
   unsigned long long save;
   uint32_t n, rank, slot, t;
-  enable = __builtin_amdgcn_readfirstlane(enable);
+  q1_head = __builtin_amdgcn_readfirstlane(q1_head);
+  q1_count = __builtin_amdgcn_readfirstlane(q1_count);
   asm volatile(
-      "s_mov_b32 %[n], 0\n\t"
-      "s_mov_b64 %[full], 0\n\t"
-      "s_mov_b64 %[tail], 0\n\t"
-      "s_cmp_eq_u32 %[en], 0\n\t"
-      "s_cbranch_scc1 9f\n\t"
-      "v_cmp_eq_u32_e32 vcc, 0, %[lrem]\n\t"            // idle lanes
-      "s_bcnt1_i32_b64 %[n], vcc\n\t"
-      "s_min_u32 %[n], %[n], %[qc]\n\t"
-      "s_cmp_eq_u32 %[n], 0\n\t"
-      "s_cbranch_scc1 1f\n\t"
-      "v_mbcnt_lo_u32_b32 %[rank], vcc_lo, 0\n\t"
-      "v_mbcnt_hi_u32_b32 %[rank], vcc_hi, %[rank]\n\t"
       "s_mov_b64 %[save], exec\n\t"
-      "s_mov_b64 exec, vcc\n\t"
-      "v_cmpx_gt_u32_e32 vcc, %[n], %[rank]\n\t"         // the first n idle lanes
-      "v_add_u32 %[slot], %[head], %[rank]\n\t"          // < 96 + 64
-      "v_subrev_u32 %[t], 96, %[slot]\n\t"
-      "v_min_u32 %[slot], %[slot], %[t]\n\t"
-      "v_lshl_add_u32 %[slot], %[slot], 3, %[q1]\n\t"
-      "ds_read_b64 %[cr], %[slot]\n\t"
-      "ds_read_b64 %[ci], %[slot] offset:768\n\t"
-      "ds_read_b64 %[r], %[slot] offset:1536\n\t"
-      "ds_read_b64 %[i], %[slot] offset:2304\n\t"
-      "ds_read_b64 %[sr], %[slot] offset:1536\n\t"      // the saved point of the periodicity check = z
-      "ds_read_b64 %[si], %[slot] offset:2304\n\t"
-      "v_mov_b32 %[lrem], %[ls]\n\t"
-      "s_mov_b64 exec, %[save]\n\t"
-      "1:\n\t"
-      "v_cmp_le_u32_e32 vcc, " CB_CHUNK_S ", %[lrem]\n\t"
-      "v_cmp_eq_u32_e64 %[tail], %[tv], %[lrem]\n\t"
-      "s_mov_b64 %[full], vcc\n\t"
+      CBW_REFILL_SLOT(0) CBW_REFILL_SLOT(1) CBW_REFILL_SLOT(2) CBW_REFILL_SLOT(3)
       "s_waitcnt lgkmcnt(0)\n\t"
-      "9:\n\t"
-      : [cr] "+v"(o.cr), [ci] "+v"(o.ci), [r] "+v"(o.r), [i] "+v"(o.i), [sr] "+v"(seen_r), [si] "+v"(seen_i),
-        [lrem] "+v"(l_rem), [n] "=&s"(n), [full] "=&s"(full), [tail] "=&s"(tail), [save] "=&s"(save),
+      : [cr0] "+v"(o[0].cr), [ci0] "+v"(o[0].ci), [r0] "+v"(o[0].r), [i0] "+v"(o[0].i), [sr0] "+v"(seen_r[0]),
+        [si0] "+v"(seen_i[0]), [lrem0] "+v"(l_rem[0]),
+        [cr1] "+v"(o[1].cr), [ci1] "+v"(o[1].ci), [r1] "+v"(o[1].r), [i1] "+v"(o[1].i), [sr1] "+v"(seen_r[1]),
+        [si1] "+v"(seen_i[1]), [lrem1] "+v"(l_rem[1]),
+        [cr2] "+v"(o[2].cr), [ci2] "+v"(o[2].ci), [r2] "+v"(o[2].r), [i2] "+v"(o[2].i), [sr2] "+v"(seen_r[2]),
+        [si2] "+v"(seen_i[2]), [lrem2] "+v"(l_rem[2]),
+        [cr3] "+v"(o[3].cr), [ci3] "+v"(o[3].ci), [r3] "+v"(o[3].r), [i3] "+v"(o[3].i), [sr3] "+v"(seen_r[3]),
+        [si3] "+v"(seen_i[3]), [lrem3] "+v"(l_rem[3]),
+        [head] "+s"(q1_head), [qc] "+s"(q1_count), [n] "=&s"(n), [save] "=&s"(save),
+        [full0] "=&s"(full[0]), [full1] "=&s"(full[1]), [full2] "=&s"(full[2]), [full3] "=&s"(full[3]),
+        [tail0] "=&s"(tail[0]), [tail1] "=&s"(tail[1]), [tail2] "=&s"(tail[2]), [tail3] "=&s"(tail[3]),
         [rank] "=&v"(rank), [slot] "=&v"(slot), [t] "=&v"(t)
-      : [qc] "s"(q1_count), [head] "s"(q1_head), [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value),
-        [en] "s"(enable)
+      : [q1] "s"(q1_lds), [ls] "s"(long_steps), [tv] "s"(tail_value)
       : "vcc", "scc", "memory");
-  taken = n;
 }
 
 // long_retire (draw_wave.hip) with this kernel's Q2 ring (320 entries, q2_ci 2560 bytes on) and its iteration
@@ -914,7 +932,7 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
   uint32_t cs, ch, ctr, t, nn;
   double a, fx, fy, d0, d1, d2, d3, ox, oy;
   uint32_t pidx, e, col, row;
-  const KernelArgs ka = fresh_args();
+  const KernelArgs ka = kernel_args();
   const double wb = ka->replay_bound_w, hb = ka->replay_bound_h;  // (double) w, h: the bounds of the quotients, compared as bit patterns
   const uint32_t wi = (uint32_t) ka->w;
   const unsigned long long hist = reinterpret_cast<unsigned long long>(ka->hist);
@@ -1214,7 +1232,8 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     if (do_head) {
       uint32_t f_rejected = 0, f_too_fast = 0, f_steps = 0;
       const bool bodies = do_head && __builtin_amdgcn_readfirstlane(halves_left) != 0u;
-      if (bodies && (halves_left & 63u) == 0u) post_progress_and_set_priority(halves_left);
+      static_assert(kPrioHalves == 256, "CBW_AFTER ends the statement where halves % 256 == 0");
+      if (bodies && (halves_left & (kPrioHalves - 1u)) == 0u) post_progress_and_set_priority(halves_left);
       uint32_t count = (uint32_t) q0_count;
       if (bodies) head_bodies(1u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
                   q0_lds, f_rejected, f_too_fast, f_steps);  // survivors -> Q0
@@ -1253,7 +1272,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     // ---------------------------------------------------------------- MID (touches no lane register that lives on)
     if (do_mid) {
       const int n = (int) __builtin_amdgcn_readfirstlane((uint32_t) (q0_count < 64 ? q0_count : 64));
-      const KernelArgs ma = fresh_args();
+      const KernelArgs ma = kernel_args();
       const unsigned long long take = uniform_u64((n == 64) ? ~0ull : ((1ull << n) - 1ull));
       unsigned long long alive;
       uint32_t steps;
@@ -1270,22 +1289,18 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
 
     // ---------------------------------------------------------------- LONG
     if (do_long) {
-      const uint32_t en = 1u;
-      const KernelArgs la = fresh_args();
+      const KernelArgs la = kernel_args();
       const uint32_t long_steps_u = la->long_steps, tail_value = la->tail_value;
       if (do_long) {
         if ((long_chunks & (kPrioChunks - 1u)) == 0u) post_progress_and_set_priority(halves_left);
         ++long_chunks;
       }
       unsigned long long full_mask[kSlots], tail_mask[kSlots];
-#pragma unroll
-      for (int o = 0; o < kSlots; ++o) {  // refill idle orbit slots from Q1
-        uint32_t taken = 0;
-        long_refill(en, lo[o], seen_r[o], seen_i[o], l_rem[o], __builtin_amdgcn_readfirstlane((uint32_t) q1_head),
-                    __builtin_amdgcn_readfirstlane((uint32_t) q1_count), q1_lds, long_steps_u, tail_value, taken,
-                    full_mask[o], tail_mask[o]);
-        q1_head = q1_wrap(q1_head + (int) taken);
-        q1_count -= (int) taken;
+      {  // refill idle orbit slots from Q1
+        uint32_t head = (uint32_t) q1_head, count = (uint32_t) q1_count;
+        long_refill4(lo, seen_r, seen_i, l_rem, head, count, q1_lds, long_steps_u, tail_value, full_mask, tail_mask);
+        q1_head = (int) head;
+        q1_count = (int) count;
       }
       const unsigned long long any_full = full_mask[0] | full_mask[1] | full_mask[2] | full_mask[3];
 #pragma unroll
