@@ -1174,6 +1174,10 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     pending = 1u;
   }
 
+  // Everything loaded so far (generators, carried state) has arrived before the loop begins: a wait for it inside the
+  // loop would also wait, every time round, for the pixel stream's stores of the bursts before (vmcnt counts both).
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+
   // ONE stage action per iteration, in the order of precedence REPLAY > HEAD > MID > LONG.  The statements that write
   // lane registers are executed in EVERY iteration and told by a scalar whether to do anything (head_bodies).
   for (;;) {
