@@ -796,7 +796,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_div_fixup_f64 " q ", %[d0], " den ", " num "\n\t"
 // (draw_wave.hip, CB_REPLAY_BIN_DIV: the estimate RN(a * RN(1/d)) decides unless its fraction is within 2^-24 of
 // an integer; then the whole wave takes the IEEE division)
-#define CBW_REPLAY_BIN_DIV                                \
+#define CBW_REPLAY_BIN_DIV CBW_REPLAY_BIN_DIV_L("4", "5")
+#define CBW_REPLAY_BIN_DIV2 CBW_REPLAY_BIN_DIV_L("14", "15")
+#define CBW_REPLAY_BIN_DIV_L(LA, LB)                      \
   "v_fma_f64 %[fx], %[r], 0.5, -%[ox]\n\t"                \
   "v_fma_f64 %[fy], %[i], 0.5, -%[oy]\n\t"                \
   "v_mul_f64 %[d0], %[fx], %[rx]\n\t"                     \
@@ -861,15 +863,17 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_cbranch_scc0 2f\n\t"
 #define CBW_REPLAY_HEAD                                   \
   "s_mov_b32 %[ctr], %[n]\n\t"                            \
+  "s_mov_b32 %[ch], %[fill]\n\t"        /* (the hits of the burst: fill afterwards - fill before) */ \
   "s_mov_b64 exec, %[act]\n\t"                            \
   "v_mul_f64 %[a], %[r], %[r]\n\t"      /* |Z_n|^2 of the pending point, as the step that made it computed it */ \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "s_cmp_lg_u32 %[direct], 0\n\t"                         \
+  "s_cbranch_scc1 7f\n\t"                                 \
   "1:\n\t"                                                \
-  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
-  "s_add_u32 %[clk], %[clk], 1\n\t"
-// `direct` != 0 (the wave's stream region is full): the hits add to the histogram with device-scope atomics instead
-// (a one-level canvas has at most 2^24 pixels: the byte offset of a pixel fits 32 bits)
-#define CBW_REPLAY_LOOP                                   \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"
+// The loop's tail.  As few scalar instructions and taken branches as it can do with: at two waves per SIMD nothing
+// hides them (one taken branch per step, the back edge).
+#define CBW_REPLAY_STEP_COMMON                            \
   "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
@@ -879,9 +883,9 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t" \
   "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
-  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
-  "s_cmp_lg_u32 %[direct], 0\n\t"                         \
-  "s_cbranch_scc1 7f\n\t"                                 \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"
+#define CBW_REPLAY_LOOP                                   \
+  CBW_REPLAY_STEP_COMMON                                  \
   "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
@@ -894,8 +898,24 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_mov_b64 exec, vcc\n\t"                               \
   "global_store_dword %[pidx], %[e], %[base]\n\t"         \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
-  "s_branch 8f\n\t"                                       \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "s_cbranch_execz 8f\n\t"                                \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
+  "s_cbranch_scc1 1b\n\t"                                 \
+  "8:\n\t"                                                \
+  "s_sub_u32 %[ch], %[fill], %[ch]\n\t"
+// `direct` != 0 (the wave's stream region is full; rare): the same loop with the hits added to the histogram by
+// device-scope atomics (a one-level canvas has at most 2^24 pixels: the byte offset of a pixel fits 32 bits).  BIN:
+// the text that forms fx, fy (a second copy of it).
+#define CBW_REPLAY_DIRECT(BIN)                            \
+  "s_branch 9f\n\t"                                       \
   "7:\n\t"                                                \
+  "s_mov_b32 %[ch], 0\n\t"                                \
+  "3:\n\t"                                                \
+  "s_bcnt1_i32_b64 %[t], %[act]\n\t"                      \
+  BIN                                                     \
+  CBW_REPLAY_STEP_COMMON                                  \
   "v_mad_u32_u24 %[pidx], %[row], %[wi], %[col]\n\t"      \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
@@ -906,13 +926,19 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_and_b64 %[act], %[act], %[alive]\n\t"                \
   "s_mov_b64 exec, vcc\n\t"                               \
   "global_atomic_add_x2 %[pidx], %[fx], %[hist]\n\t"      \
-  "8:\n\t"                                                \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
   "s_mov_b64 exec, %[act]\n\t"                            \
-  "s_cbranch_execz 2f\n\t"                                \
+  "s_cbranch_execz 9f\n\t"                                \
   "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
   "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
-  "s_cbranch_scc1 1b\n\t"                                 \
+  "s_cbranch_scc1 3b\n\t"                                 \
+  "9:\n\t"
+// behind either loop: the clock moves on by the steps made (n - ctr, and one more if the last lane left before the
+// count was taken down); then the way out that the skipped forms share
+#define CBW_REPLAY_END                                    \
+  "s_sub_u32 %[t], %[n], %[ctr]\n\t"                      \
+  "s_cmp_eq_u64 %[act], 0\n\t"                            \
+  "s_addc_u32 %[clk], %[clk], %[t]\n\t"                   \
   "2:\n\t"                                                \
   "s_mov_b64 exec, %[save]\n\t"                           \
   "s_nop 4\n\t"
@@ -964,6 +990,7 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
     asm volatile("v_mov_b64 %[ox], %[oxs]\n\t"  // (in every lane: EXEC is all ones here, not behind the refill)
                  "v_mov_b64 %[oy], %[oys]\n\t"
                  CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
+                 CBW_REPLAY_DIRECT(CBW_REPLAY_BIN_POW2) CBW_REPLAY_END
                  : CBW_REPLAY_OUT, [ox] "=&v"(ox), [oy] "=&v"(oy)
                  : CBW_REPLAY_IN, [oxs] "s"(oxs), [oys] "s"(oys)
                  : "vcc", "scc", "memory");
@@ -971,6 +998,7 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
     const double kg = 0.5 - 0x1p-24;
     asm volatile(CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_DIV CBW_REPLAY_LOOP
+                 CBW_REPLAY_DIRECT(CBW_REPLAY_BIN_DIV2) CBW_REPLAY_END
                  : CBW_REPLAY_OUT, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
                  : CBW_REPLAY_IN, [ox] "s"(oxs), [oy] "s"(oys), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
                  : "vcc", "scc", "memory");
