@@ -1149,11 +1149,11 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     const bool before_me = (lane < 16u) && (lane != (wave_slot & 15u)) &&
                            (other > mine || (other == mine && lane < (wave_slot & 15u)));
     const int rank = __popcll(__ballot(before_me));
-    // (the scatter's waves beside these run at priority 0: they issue little and wait for memory)
+    // (the scatter's waves beside these run at priority 3: they issue little and wait for memory a lot)
     if (rank == 0) {
-      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_s_setprio(1);
     } else {
-      __builtin_amdgcn_s_setprio(2);
+      __builtin_amdgcn_s_setprio(0);
     }
   };
   const uint32_t keep_rest = __builtin_amdgcn_readfirstlane(a.drain ? 1u : 0u);  // 0: leave in-flight work to the next launch
