@@ -63,6 +63,12 @@ constexpr int kHeadSteps = 4;
 constexpr int kQ1Low = CB_WQ1_LOW;      // run MID while fewer deep orbits than this are queued
 constexpr int kReplayMin = CB_WREPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = CB_WREPLAY_BURST;  // replay steps per asm burst
+#ifndef CB_WIDE_PRIO_BEHIND
+#define CB_WIDE_PRIO_BEHIND 2  // s_setprio of the wave of a SIMD that has more left to draw ...
+#endif
+#ifndef CB_WIDE_PRIO_AHEAD
+#define CB_WIDE_PRIO_AHEAD 1   // ... and of the other
+#endif
 constexpr uint32_t kBrentBits = 2;      // periodicity check: re-save when the chunk count has no bits below its top 2
 constexpr uint32_t kPrioChunks = 64;    // LONG chunks between two looks at the progress board (power of two)
 constexpr uint32_t kPrioHalves = 256;   // HEAD half-passes between two looks (power of two; a look costs a round trip to L2)
@@ -1149,11 +1155,11 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     const bool before_me = (lane < 16u) && (lane != (wave_slot & 15u)) &&
                            (other > mine || (other == mine && lane < (wave_slot & 15u)));
     const int rank = __popcll(__ballot(before_me));
-    // (the scatter's waves beside these run at priority 3: they issue little and wait for memory a lot)
+    // (the scatter's waves beside these: scatter.hip, CB_SCATTER_PRIO)
     if (rank == 0) {
-      __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(CB_WIDE_PRIO_BEHIND);
     } else {
-      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(CB_WIDE_PRIO_AHEAD);
     }
   };
   const uint32_t keep_rest = __builtin_amdgcn_readfirstlane(a.drain ? 1u : 0u);  // 0: leave in-flight work to the next launch

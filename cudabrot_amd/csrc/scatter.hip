@@ -39,6 +39,11 @@
 
 #include "kernels.h"
 
+// priority of the sort / gather waves (0..3; tools/gpu_wide_prio.sh sweeps it against draw_wide.hip's CB_WIDE_PRIO_*)
+#ifndef CB_SCATTER_PRIO
+#define CB_SCATTER_PRIO 1
+#endif
+
 namespace cb {
 
 namespace {
@@ -302,7 +307,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
   // Beside the two-waves-per-SIMD draw kernel (draw_wide.hip) these waves share their SIMDs with draw waves that
   // never wait for memory: the scatter issues little and waits a lot, so it goes first when it can issue.
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(CB_SCATTER_PRIO);
   extern __shared__ uint32_t lds[];
   uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
@@ -469,7 +474,7 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
                                                                             unsigned long long *hist,
                                                                             int w, int h) {
   __shared__ uint32_t tile[kTilePixels];  // 64 KiB
-  __builtin_amdgcn_s_setprio(3);  // (see bin_region_sort_kernel)
+  __builtin_amdgcn_s_setprio(CB_SCATTER_PRIO);  // (see bin_region_sort_kernel)
   // which (tile, slice) is this workgroup?  slice_base is an exclusive prefix: binary search
   const uint32_t s = blockIdx.x;
   if (s >= b.slice_base[b.n_tiles]) return;  // the grid is an upper bound
