@@ -4,10 +4,10 @@ set -u
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 B="--steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
-for v in wide nowide; do
+for v in ${VARIANTS:-wide nowide}; do
   rm -rf gpurun_out/pmc_$v
   if [ $v = nowide ]; then export CUDABROT_AMD_DEBUG=1 CUDABROT_AMD_NO_WIDE=1; else unset CUDABROT_AMD_NO_WIDE; fi
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_$v -- python3 bench.py $B > gpurun_out/pmc_$v.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE} --output-format csv -d gpurun_out/pmc_$v -- python3 bench.py $B > gpurun_out/pmc_$v.log 2>&1
   echo "== $v exit $?"
   python3 - gpurun_out/pmc_$v <<'PY'
 import csv,glob,sys,collections
