@@ -181,12 +181,11 @@ __device__ __forceinline__ unsigned long long iterate_steps(unsigned long long m
 // out = d + k * 362437 + new word.
 #define CBW_D1(xk) "v_lshrrev_b32 %[t], 2, " xk "\n\t"
 #define CBW_D2(xp) "v_lshlrev_b32 %[u], 4, " xp "\n\t"
-#define CBW_DS(ck) "s_mov_b32 %[sc], " ck "\n\t"
 #define CBW_D3(xk) "v_xor_b32 %[t], %[t], " xk "\n\t"
 #define CBW_D4(xk) "v_lshlrev_b32 " xk ", 1, %[t]\n\t"
 #define CBW_D5(xp) "v_bitop3_b32 %[u], %[u], " xp ", %[t] bitop3:0x96\n\t"
 #define CBW_D6(xk) "v_xor_b32 " xk ", %[u], " xk "\n\t"
-#define CBW_D7(xk, xd, out) "v_add3_u32 " out ", " xd ", " xk ", %[sc]\n\t"
+#define CBW_D7(xk, xd, out, kw) "v_add3_u32 " out ", " xd ", " xk ", " kw "\n\t"  /* kw: k times the Weyl increment, in a scalar */
 static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u == 0x10974fu &&
                   4u * 362437u == 0x161f14u,
               "multiples of the Weyl increment (rocrand_xorwow.h:174)");
@@ -208,21 +207,23 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 #define CBW_T4
 #define CBW_T5
 #define CBW_T6
-#define CBW_T7 "s_mov_b64 %[m0], -1\n\t"
+#define CBW_T7
+#define CBW_T7S "s_mov_b64 %[m0], -1\n\t"
 #define CBW_T8
-#define CBW_T9 "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
+#define CBW_T9
+#define CBW_T9S "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
 #else
 #define CBW_T2 "v_add_f64 %[x], %[cr], -0.5\n\t"             /* X = 2 (re - 1/4) */
 #define CBW_T3 "v_add_f64 %[r], %[cr], 2.0\n\t"              /* T = 2 (re + 1) */
 #define CBW_T4 "v_fma_f64 %[q], %[x], %[x], %[a]\n\t"        /* Q */
 #define CBW_T5 "v_fma_f64 %[r], %[r], %[r], %[a]\n\t"        /* bulb: fma(T,T,II) */
 #define CBW_T6 "v_fma_f64 %[x], %[x], 2.0, %[q]\n\t"         /* S */
-#define CBW_T7 "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t" /* !(bulb < 1/4) */ \
-               "s_mov_b64 %[m0], vcc\n\t"
+#define CBW_T7 "v_cmp_ngt_f64_e32 vcc, 0x3fd00000, %[r]\n\t" /* !(bulb < 1/4) */
+#define CBW_T7S "s_mov_b64 %[m0], vcc\n\t"
 #define CBW_T8 "v_mul_f64 %[q], %[q], %[x]\n\t"              /* Q * S */
-#define CBW_T9 "v_cmp_nlt_f64_e64 %[m1], %[q], %[a]\n\t"     /* !(Q*S < II) */ \
-               "s_and_b64 %[m0], %[m0], %[m1]\n\t"                               \
-               "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
+#define CBW_T9 "v_cmp_nlt_f64_e64 %[m1], %[q], %[a]\n\t"     /* !(Q*S < II) */
+#define CBW_T9S "s_and_b64 %[m0], %[m0], %[m1]\n\t"                              \
+                "s_bcnt1_i32_b64 %[cnt], %[m0]\n\t"
 #endif
 #define CBW_T1 "v_mul_f64 %[a], %[ci], %[ci]\n\t"            /* II */
 // step 1 from z = c; its first product I*I is II
@@ -254,50 +255,53 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 
 // One body: the test of the pending sample (cr, ci) interleaved with the draw of the next one from the generator
 // whose logical words x0..x4 are X0..X4 and whose Weyl value is XD.
+// (A scalar instruction that reads what a compare wrote sits at least three instructions behind it: the wave has no
+// other wave's instructions to fill the forwarding latency with.)
 #define CBW_BODY(X0, X1, X2, X3, X4, XD)                                   \
-  CBW_T1 CBW_D1(X0) CBW_T2 CBW_D2(X4) CBW_DS("0x587c5")                    \
+  CBW_T1 CBW_D1(X0) CBW_T2 CBW_D2(X4)                                      \
   CBW_T3 CBW_D3(X0) CBW_T4 CBW_D4(X0) CBW_T5 CBW_D5(X4)                    \
-  CBW_T6 CBW_D6(X0) CBW_T7 CBW_D7(X0, XD, "%[o1]")                         \
-  CBW_T8 CBW_D1(X1) CBW_T9 CBW_D2(X0) CBW_DS("0xb0f8a")                    \
-  CBW_S1A CBW_D3(X1) CBW_S1B CBW_D4(X1) CBW_SC CBW_D5(X0)                  \
-  CBW_SD CBW_D6(X1) CBW_SE CBW_D7(X1, XD, "%[o2]")                         \
-  CBW_SF CBW_C1("%[nr]") CBW_S1G CBW_SN0                                   \
-  CBW_SA CBW_C2 CBW_SN1 CBW_SB CBW_C3 CBW_SI CBW_D1(X2)                    \
-  CBW_SC CBW_C4("%[nr]") CBW_SD CBW_D2(X1) CBW_DS("0x10974f")              \
-  CBW_SE CBW_D3(X2) CBW_SF CBW_D4(X2) CBW_SG CBW_SN0                       \
-  CBW_SA CBW_D5(X1) CBW_SN1 CBW_SB CBW_D6(X2) CBW_SI CBW_D7(X2, XD, "%[o1]") \
-  CBW_SC CBW_D1(X3) CBW_SD CBW_D2(X2) CBW_DS("0x161f14")                   \
-  CBW_SE CBW_D3(X3) CBW_SF CBW_D4(X3) CBW_SG CBW_SN0                       \
-  CBW_SA CBW_D5(X2) CBW_SN1 CBW_SB CBW_D6(X3) CBW_SI CBW_D7(X3, XD, "%[o2]") \
-  CBW_SC "v_add_u32 " XD ", %[sc], " XD "\n\t"                             \
-  CBW_SD CBW_C1("%[ni]") CBW_SE CBW_C2 CBW_SF CBW_C3                       \
-  CBW_SG CBW_P0 CBW_P1 CBW_C4("%[ni]") CBW_P2 CBW_P3 CBW_P4 CBW_P5 CBW_P6  \
+  CBW_T6 CBW_D6(X0) CBW_T7 CBW_D7(X0, XD, "%[o1]", "%[k1]")                \
+  CBW_T8 CBW_D1(X1) CBW_D2(X0) CBW_T7S CBW_T9 CBW_D3(X1)                   \
+  CBW_S1A CBW_D4(X1) CBW_S1B CBW_T9S CBW_SC CBW_D5(X0)                     \
+  CBW_SD CBW_D6(X1) CBW_SE CBW_D7(X1, XD, "%[o2]", "%[k2]")                \
+  CBW_SF CBW_C1("%[nr]") CBW_C2 CBW_SA CBW_S1G CBW_C3                      \
+  CBW_SB CBW_SN0 CBW_SI CBW_D1(X2) CBW_SN1                                 \
+  CBW_SC CBW_C4("%[nr]") CBW_SD CBW_D2(X1)                                 \
+  CBW_SE CBW_D3(X2) CBW_SF CBW_D4(X2) CBW_SA CBW_D5(X1) CBW_SG             \
+  CBW_SB CBW_D6(X2) CBW_SN0 CBW_SI CBW_D7(X2, XD, "%[o1]", "%[k3]") CBW_SN1 \
+  CBW_SC CBW_D1(X3) CBW_SD CBW_D2(X2)                                      \
+  CBW_SE CBW_D3(X3) CBW_SF CBW_D4(X3) CBW_SA CBW_D5(X2) CBW_SG             \
+  CBW_SB CBW_D6(X3) CBW_SN0 CBW_SI CBW_D7(X3, XD, "%[o2]", "%[k4]") CBW_SN1 \
+  CBW_SC "v_add_u32 " XD ", %[k4], " XD "\n\t"                             \
+  CBW_SD CBW_C1("%[ni]") CBW_SE CBW_C2 CBW_SF CBW_C3 CBW_C4("%[ni]")       \
+  "s_bcnt1_i32_b64 %[tmp], %[m0]\n\t"                                      \
+  "s_add_u32 %[acc0], %[acc0], %[tmp]\n\t"  /* lanes outside both regions, summed over the bodies */ \
+  "s_add_u32 %[steps], %[steps], %[cnt]\n\t"                               \
+  CBW_SG CBW_P0 CBW_P1 CBW_P2 CBW_P3 CBW_P4 CBW_P5 CBW_P6                  \
   "v_fma_f64 %[cr], %[nr], %[k2m50], %[kk]\n\t"                            \
   "v_fma_f64 %[ci], %[ni], %[k2m50], %[kk]\n\t"
 
-// Behind a body: its statistics, the ring, the state, and whether the next body runs.  The statement ends behind the
-// body after which  the input has ended (halves == 0: the pending sample is the launch's last, the caller tests it),
-// or Q0 holds a MID pass (q0_count >= 64),  or the progress board is due (halves % 256 == 0).
-#define CBW_AFTER(next_hs, next_label)                               \
-  "s_bcnt1_i32_b64 %[tmp], %[m0]\n\t"                                \
-  "s_sub_u32 %[rej], %[rej], %[tmp]\n\t"  /* rejected: 64 - alive0 */ \
-  "s_add_u32 %[rej], %[rej], 64\n\t"                                 \
-  "s_add_u32 %[fast], %[fast], %[tmp]\n\t" /* escaped in HEAD: alive0 - alive4 */ \
+// Behind a body: the ring, and whether the next body runs.  The statement ends behind the body after which  the
+// input has ended (halves == 0: the pending sample is the launch's last, the caller tests it),  or Q0 holds a MID
+// pass (q0_count >= 64),  or the progress board is due (halves % 256 == 0) -- one test and one branch for the three;
+// the state (hs) is set on the way out only (the stubs CBW_EXIT).  rejected / escaped-in-HEAD are made from acc0 and
+// the growth of q0_count behind the loop.
+#define CBW_AFTER(exit_label, next_label)                            \
   "s_bcnt1_i32_b64 %[tmp], %[m1]\n\t"                                \
-  "s_sub_u32 %[fast], %[fast], %[tmp]\n\t"                           \
-  "s_add_u32 %[steps], %[steps], %[cnt]\n\t"                         \
+  "s_sub_u32 %[halves], %[halves], 1\n\t"                            \
   "s_add_u32 %[q0c], %[q0c], %[tmp]\n\t"                             \
   "s_add_u32 %[tail], %[tail], %[tmp]\n\t"                           \
-  "s_sub_u32 %[halves], %[halves], 1\n\t"                            \
-  "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
-  "s_cmp_eq_u32 %[halves], 0\n\t"                                    \
-  "s_cbranch_scc1 99f\n\t"                                           \
-  "s_cmp_ge_u32 %[q0c], 64\n\t"                                      \
-  "s_cbranch_scc1 99f\n\t"                                           \
-  "s_and_b32 %[tmp], %[halves], 255\n\t"                             \
+  "s_and_b32 %[tmp], %[halves], 255\n\t"     /* 0: the board is due */ \
+  "s_min_u32 %[tmp], %[tmp], %[halves]\n\t"  /* 0: the input has ended */ \
+  "s_cmp_lt_u32 %[q0c], 64\n\t"                                      \
+  "s_cselect_b32 %[tmp], %[tmp], 0\n\t"      /* 0: Q0 holds a MID pass */ \
   "s_cmp_eq_u32 %[tmp], 0\n\t"                                       \
-  "s_cbranch_scc1 99f\n\t"                                           \
+  "s_cbranch_scc1 " exit_label "f\n\t"                               \
   next_label
+#define CBW_EXIT(label, next_hs)                                     \
+  label ":\n\t"                                                      \
+  "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
+  "s_branch 99f\n\t"
 
 #define CBW_GA(k) "%[a" #k "]"
 #define CBW_GB(k) "%[b" #k "]"
@@ -321,7 +325,7 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
                                             uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
   static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CBW_P4 / CBW_P6");
   unsigned long long save, m0, m1;
-  uint32_t cnt, tmp, sc, slot, t, u, o1, o2;
+  uint32_t cnt, tmp, slot, t, u, o1, o2, acc0 = 0;
   double a, r, i, x, q, f, nr, ni, kk;
   enable = __builtin_amdgcn_readfirstlane(enable);
   halves = __builtin_amdgcn_readfirstlane(halves);
@@ -331,6 +335,7 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
   n_rejected = __builtin_amdgcn_readfirstlane(n_rejected);
   n_too_fast = __builtin_amdgcn_readfirstlane(n_too_fast);
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
+  const uint32_t halves_before = halves, q0_before = q0_count;
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_cmp_eq_u32 %[en], 0\n\t"
@@ -360,28 +365,35 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
       "s_cmp_eq_u32 %[hs], 8\n\t"
       "s_cbranch_scc1 18f\n\t"
       "s_branch 19f\n\t"
-      "10:\n\t" CBW_BODY_A(0, 1, 2, 3, 4) CBW_AFTER("1", "11:\n\t")  // rot 0
-      CBW_BODY_B(0, 1, 2, 3, 4) CBW_AFTER("2", "12:\n\t")
-      CBW_BODY_A(4, 0, 1, 2, 3) CBW_AFTER("3", "13:\n\t")            // rot 4
-      CBW_BODY_B(4, 0, 1, 2, 3) CBW_AFTER("4", "14:\n\t")
-      CBW_BODY_A(3, 4, 0, 1, 2) CBW_AFTER("5", "15:\n\t")            // rot 3
-      CBW_BODY_B(3, 4, 0, 1, 2) CBW_AFTER("6", "16:\n\t")
-      CBW_BODY_A(2, 3, 4, 0, 1) CBW_AFTER("7", "17:\n\t")            // rot 2
-      CBW_BODY_B(2, 3, 4, 0, 1) CBW_AFTER("8", "18:\n\t")
-      CBW_BODY_A(1, 2, 3, 4, 0) CBW_AFTER("9", "19:\n\t")            // rot 1
-      CBW_BODY_B(1, 2, 3, 4, 0) CBW_AFTER("0", "s_branch 10b\n\t")
+      "10:\n\t" CBW_BODY_A(0, 1, 2, 3, 4) CBW_AFTER("81", "11:\n\t")  // rot 0
+      CBW_BODY_B(0, 1, 2, 3, 4) CBW_AFTER("82", "12:\n\t")
+      CBW_BODY_A(4, 0, 1, 2, 3) CBW_AFTER("83", "13:\n\t")            // rot 4
+      CBW_BODY_B(4, 0, 1, 2, 3) CBW_AFTER("84", "14:\n\t")
+      CBW_BODY_A(3, 4, 0, 1, 2) CBW_AFTER("85", "15:\n\t")            // rot 3
+      CBW_BODY_B(3, 4, 0, 1, 2) CBW_AFTER("86", "16:\n\t")
+      CBW_BODY_A(2, 3, 4, 0, 1) CBW_AFTER("87", "17:\n\t")            // rot 2
+      CBW_BODY_B(2, 3, 4, 0, 1) CBW_AFTER("88", "18:\n\t")
+      CBW_BODY_A(1, 2, 3, 4, 0) CBW_AFTER("89", "19:\n\t")            // rot 1
+      CBW_BODY_B(1, 2, 3, 4, 0) CBW_AFTER("80", "s_branch 10b\n\t")
+      CBW_EXIT("81", "1") CBW_EXIT("82", "2") CBW_EXIT("83", "3") CBW_EXIT("84", "4") CBW_EXIT("85", "5")
+      CBW_EXIT("86", "6") CBW_EXIT("87", "7") CBW_EXIT("88", "8") CBW_EXIT("89", "9") CBW_EXIT("80", "0")
       "99:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "s_nop 4\n\t"
-      : [halves] "+s"(halves), [hs] "+s"(hs), [tail] "+s"(q0_tail), [q0c] "+s"(q0_count), [rej] "+s"(n_rejected),
-        [fast] "+s"(n_too_fast), [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
-        [save] "=&s"(save), [tmp] "=&s"(tmp), [sc] "=&s"(sc), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
+      : [halves] "+s"(halves), [hs] "+s"(hs), [tail] "+s"(q0_tail), [q0c] "+s"(q0_count), [acc0] "+s"(acc0),
+        [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
+        [save] "=&s"(save), [tmp] "=&s"(tmp), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
         [q] "=&v"(q), [slot] "=&v"(slot), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
         [nr] "=&v"(nr), [ni] "=&v"(ni), [kk] "=&v"(kk), [cr] "+v"(cr), [ci] "+v"(ci),
         [a0] "+v"(g.a.x0), [a1] "+v"(g.a.x1), [a2] "+v"(g.a.x2), [a3] "+v"(g.a.x3), [a4] "+v"(g.a.x4), [ad] "+v"(g.a.d),
         [b0] "+v"(g.b.x0), [b1] "+v"(g.b.x1), [b2] "+v"(g.b.x2), [b3] "+v"(g.b.x3), [b4] "+v"(g.b.x4), [bd] "+v"(g.b.d)
-      : [en] "s"(enable), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50)
+      : [en] "s"(enable), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50), [k1] "s"(362437u), [k2] "s"(2u * 362437u),
+        [k3] "s"(3u * 362437u), [k4] "s"(4u * 362437u)
       : "vcc", "scc", "memory");
+  // rejected: the lanes inside a region; escaped in HEAD (too fast): outside both regions and not among the survivors
+  const uint32_t bodies = halves_before - halves, survivors = q0_count - q0_before;
+  n_rejected += 64u * bodies - acc0;
+  n_too_fast += acc0 - survivors;
 }
 
 // logical word j of a generator whose words are rotated by ROT (field (j + ROT) % 5), and back
@@ -438,6 +450,18 @@ __device__ __forceinline__ Xorwow xorwow_rotated4(const Xorwow &s) {
   "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
   "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
+// the same with the lane count taken behind the step's first instruction (which waits for the EXEC of the compare
+// before it anyway)
+#define CBW_MID_STEP                                  \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
+  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
+  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
+  "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
 #define CB_STEP_NOTEST                                \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
@@ -467,11 +491,21 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "v_fma_f64 %[i], " CB_AL "%[cr]" CB_AR ", " CB_AL "%[ci]" CB_AR ", %[ci]\n\t"
       "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
       CB_STEP_NOTEST CB_STEP_NOTEST CB_STEP_NOTEST
-      "s_cmp_eq_u32 %[n], 0\n\t"
+      // the steps in groups of four (one look at EXEC and one taken branch per group: at two waves per SIMD nothing
+      // hides the scalar unit's wait for the compare), then what is left one by one
+      "s_cmp_lt_u32 %[ctr], 4\n\t"
+      "s_cbranch_scc1 3f\n\t"
+      "4:\n\t"
+      CBW_MID_STEP CBW_MID_STEP CBW_MID_STEP CBW_MID_STEP
+      "s_sub_u32 %[ctr], %[ctr], 4\n\t"
+      "s_cbranch_execz 2f\n\t"
+      "s_cmp_ge_u32 %[ctr], 4\n\t"
+      "s_cbranch_scc1 4b\n\t"
+      "3:\n\t"
+      "s_cmp_eq_u32 %[ctr], 0\n\t"
       "s_cbranch_scc1 2f\n\t"
       "1:\n\t"
-      CB_STEP_LIT
-      "s_cbranch_execz 2f\n\t"
+      CBW_MID_STEP
       "s_sub_u32 %[ctr], %[ctr], 1\n\t"
       "s_cmp_lg_u32 %[ctr], 0\n\t"
       "s_cbranch_scc1 1b\n\t"
@@ -868,7 +902,7 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_cmp_ge_u32 %[t], %[ctr]\n\t"                       \
   "s_cbranch_scc0 2f\n\t"
 #define CBW_REPLAY_HEAD                                   \
-  "s_mov_b32 %[ctr], %[n]\n\t"                            \
+  "s_sub_u32 %[ctr], %[n], 1\n\t"       /* the loop below runs ctr + 1 = n steps */ \
   "s_mov_b32 %[ch], %[fill]\n\t"        /* (the hits of the burst: fill afterwards - fill before) */ \
   "s_mov_b64 exec, %[act]\n\t"                            \
   "v_mul_f64 %[a], %[r], %[r]\n\t"      /* |Z_n|^2 of the pending point, as the step that made it computed it */ \
@@ -883,18 +917,18 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
   "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
-  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
-  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
-  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
-  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t" \
   "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t" \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
-  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"
 #define CBW_REPLAY_LOOP                                   \
   CBW_REPLAY_STEP_COMMON                                  \
-  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
   "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
   "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
@@ -905,11 +939,15 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "global_store_dword %[pidx], %[e], %[base]\n\t"         \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
   "s_mov_b64 exec, %[act]\n\t"                            \
-  "s_cbranch_execz 8f\n\t"                                \
-  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
-  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
-  "s_cbranch_scc1 1b\n\t"                                 \
+  "s_cbranch_execz 8f\n\t"              /* (not taken but once) */ \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"     /* scc = borrow: the count had reached 0 */ \
+  "s_cbranch_scc0 1b\n\t"                                 \
+  "s_add_u32 %[clk], %[clk], %[n]\n\t"  /* the clock moves on by the steps made: all n ... */ \
+  "s_branch 18f\n\t"                                      \
   "8:\n\t"                                                \
+  "s_sub_u32 %[t], %[n], %[ctr]\n\t"    /* ... or, the last lane gone in step j = n - ctr, that many */ \
+  "s_add_u32 %[clk], %[clk], %[t]\n\t"                    \
+  "18:\n\t"                                               \
   "s_sub_u32 %[ch], %[fill], %[ch]\n\t"
 // `direct` != 0 (the wave's stream region is full; rare): the same loop with the hits added to the histogram by
 // device-scope atomics (a one-level canvas has at most 2^24 pixels: the byte offset of a pixel fits 32 bits).  BIN:
@@ -934,17 +972,17 @@ __device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, doub
   "global_atomic_add_x2 %[pidx], %[fx], %[hist]\n\t"      \
   "s_add_u32 %[ch], %[ch], %[t]\n\t"                      \
   "s_mov_b64 exec, %[act]\n\t"                            \
-  "s_cbranch_execz 9f\n\t"                                \
+  "s_cbranch_execz 19f\n\t"                               \
   "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
-  "s_cmp_lg_u32 %[ctr], 0\n\t"                            \
-  "s_cbranch_scc1 3b\n\t"                                 \
-  "9:\n\t"
-// behind either loop: the clock moves on by the steps made (n - ctr, and one more if the last lane left before the
-// count was taken down); then the way out that the skipped forms share
-#define CBW_REPLAY_END                                    \
+  "s_cbranch_scc0 3b\n\t"                                 \
+  "s_add_u32 %[clk], %[clk], %[n]\n\t"                    \
+  "s_branch 9f\n\t"                                       \
+  "19:\n\t"                                               \
   "s_sub_u32 %[t], %[n], %[ctr]\n\t"                      \
-  "s_cmp_eq_u64 %[act], 0\n\t"                            \
-  "s_addc_u32 %[clk], %[clk], %[t]\n\t"                   \
+  "s_add_u32 %[clk], %[clk], %[t]\n\t"                    \
+  "9:\n\t"
+// behind either loop: the way out that the skipped forms share
+#define CBW_REPLAY_END                                    \
   "2:\n\t"                                                \
   "s_mov_b64 exec, %[save]\n\t"                           \
   "s_nop 4\n\t"
