@@ -41,7 +41,18 @@
 
 // priority of the sort / gather waves (0..3; tools/gpu_wide_prio.sh sweeps it against draw_wide.hip's CB_WIDE_PRIO_*)
 #ifndef CB_SCATTER_PRIO
-#define CB_SCATTER_PRIO 1
+#define CB_SCATTER_PRIO 0
+#endif
+// ... of the region sort while it reads its region / writes its image (few instructions, long waits: worth issuing
+// early), while it ranks (most of its vector and LDS instructions), and of the gather
+#ifndef CB_SORT_PRIO_IO
+#define CB_SORT_PRIO_IO CB_SCATTER_PRIO
+#endif
+#ifndef CB_SORT_PRIO_RANK
+#define CB_SORT_PRIO_RANK CB_SCATTER_PRIO
+#endif
+#ifndef CB_GATHER_PRIO
+#define CB_GATHER_PRIO CB_SCATTER_PRIO
 #endif
 
 namespace cb {
@@ -307,7 +318,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
   // Beside the two-waves-per-SIMD draw kernel (draw_wide.hip) these waves share their SIMDs with draw waves that
   // never wait for memory: the scatter issues little and waits a lot, so it goes first when it can issue.
-  __builtin_amdgcn_s_setprio(CB_SCATTER_PRIO);
+  __builtin_amdgcn_s_setprio(CB_SORT_PRIO_IO);
   extern __shared__ uint32_t lds[];
   uint32_t *cnt = lds + (threadIdx.x % kCntReplicas) * kCntStride;  // this lane's replica
   uint32_t *wave_totals = lds + kCntReplicas * kCntStride;
@@ -417,6 +428,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     }
   }
   __syncthreads();
+  __builtin_amdgcn_s_setprio(CB_SORT_PRIO_RANK);
   // 2. where each tile's run starts: exclusive scan of the counts; published as run_start[tile][region]
   {
     const bool has_key = threadIdx.x < kDummyKey;  // (with few tiles most threads only take part in the scan)
@@ -448,6 +460,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     image[real ? shift + pos : kDummyPlace] = (uint16_t) e[k];
   }
   __syncthreads();
+  __builtin_amdgcn_s_setprio(CB_SORT_PRIO_IO);
   // 4. the image leaves as one linear block: image[shift + i] -> sorted[start + i]
   uint16_t *dst = b.sorted + (start - shift);  // 16-byte aligned; index = position in the image
   const uint32_t lo = shift, hi = shift + n;
@@ -474,7 +487,7 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
                                                                             unsigned long long *hist,
                                                                             int w, int h) {
   __shared__ uint32_t tile[kTilePixels];  // 64 KiB
-  __builtin_amdgcn_s_setprio(CB_SCATTER_PRIO);  // (see bin_region_sort_kernel)
+  __builtin_amdgcn_s_setprio(CB_GATHER_PRIO);  // (see bin_region_sort_kernel)
   // which (tile, slice) is this workgroup?  slice_base is an exclusive prefix: binary search
   const uint32_t s = blockIdx.x;
   if (s >= b.slice_base[b.n_tiles]) return;  // the grid is an upper bound

@@ -5,11 +5,12 @@ set -u
 mkdir -p gpurun_out
 B="--steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
 for setting in "$@"; do
-  IFS=, read -r pb pa ps <<< "$setting"
+  IFS=, read -r pb pa ps pr pg <<< "$setting"   # draw behind, draw ahead, sort i/o, sort rank, gather
+  pr=${pr:-$ps}; pg=${pg:-$ps}
   rm -f cudabrot_amd/csrc/build/draw_wide*.o cudabrot_amd/csrc/build/scatter.o
-  make -s -C cudabrot_amd/csrc all EXTRA="-DCB_WIDE_PRIO_BEHIND=$pb -DCB_WIDE_PRIO_AHEAD=$pa -DCB_SCATTER_PRIO=$ps" > gpurun_out/prio_build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/prio_build.log; exit 1; }
-  timeout -k 10 200 python3 bench.py $B > gpurun_out/prio_$pb$pa$ps.json 2> gpurun_out/prio_err.log
-  python3 - "$setting" gpurun_out/prio_$pb$pa$ps.json <<'PY'
+  make -s -C cudabrot_amd/csrc all EXTRA="-DCB_WIDE_PRIO_BEHIND=$pb -DCB_WIDE_PRIO_AHEAD=$pa -DCB_SORT_PRIO_IO=$ps -DCB_SORT_PRIO_RANK=$pr -DCB_GATHER_PRIO=$pg" > gpurun_out/prio_build.log 2>&1 || { echo "build failed"; tail -5 gpurun_out/prio_build.log; exit 1; }
+  timeout -k 10 200 python3 bench.py $B > gpurun_out/prio_$pb$pa$ps$pr$pg.json 2> gpurun_out/prio_err.log
+  python3 - "$setting" gpurun_out/prio_$pb$pa$ps$pr$pg.json <<'PY'
 import json,sys
 try:
     b=json.loads([l for l in open(sys.argv[2]) if l.startswith('{')][-1])
