@@ -64,10 +64,10 @@ constexpr int kQ1Low = CB_WQ1_LOW;      // run MID while fewer deep orbits than 
 constexpr int kReplayMin = CB_WREPLAY_MIN;  // suspend REPLAY below this many busy lanes (unless draining)
 constexpr uint32_t kReplayBurst = CB_WREPLAY_BURST;  // replay steps per asm burst
 #ifndef CB_WIDE_PRIO_BEHIND
-#define CB_WIDE_PRIO_BEHIND 3  // s_setprio of the wave of a SIMD that has more left to draw ...
+#define CB_WIDE_PRIO_BEHIND 2  // s_setprio of the wave of a SIMD that has more left to draw ...
 #endif
 #ifndef CB_WIDE_PRIO_AHEAD
-#define CB_WIDE_PRIO_AHEAD 2   // ... and of the other
+#define CB_WIDE_PRIO_AHEAD 1   // ... and of the other
 #endif
 constexpr uint32_t kBrentBits = 2;      // periodicity check: re-save when the chunk count has no bits below its top 2
 constexpr uint32_t kPrioChunks = 64;    // LONG chunks between two looks at the progress board (power of two)

@@ -46,7 +46,7 @@
 // ... of the region sort while it reads its region / writes its image (few instructions, long waits: worth issuing
 // early), while it ranks (most of its vector and LDS instructions), and of the gather
 #ifndef CB_SORT_PRIO_IO
-#define CB_SORT_PRIO_IO CB_SCATTER_PRIO
+#define CB_SORT_PRIO_IO 3   // (swept beside the wide draw kernel's 2 / 1, tools/gpu_wide_prio.sh: -5..7 % per step against 0)
 #endif
 #ifndef CB_SORT_PRIO_RANK
 #define CB_SORT_PRIO_RANK CB_SCATTER_PRIO
