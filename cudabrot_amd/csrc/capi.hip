@@ -59,6 +59,9 @@ bool exact_reciprocal(double delta, double *inv) {
   return true;
 }
 
+// Diagnostic only: which draw kernel the last cb_draw_buddhabrot* call of this process launched (cb_debug_last_draw_kernel).
+int g_last_draw_kernel = 0;
+
 // Diagnostic only (CUDABROT_AMD_WAVE_DUMP=<file> with the timed kernel variant): per-wave records of
 // the last launch, see DrawArgs::wave_dump.
 unsigned long long *g_wave_dump = nullptr;
@@ -326,6 +329,8 @@ extern "C" {
 
 int cb_abi_version(void) { return CB_ABI_VERSION; }
 
+int cb_debug_last_draw_kernel(void) { return g_last_draw_kernel; }
+
 const char *cb_error_string(int code) {
   if (code == 0) return "no error";
   if (code == CB_ERROR_KERNEL_INVARIANT) {
@@ -391,6 +396,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   // the two-waves-per-SIMD kernel where it applies (CUDABROT_AMD_NO_WIDE=1, a test knob: never)
   const bool wide = cb::draw_wide_takes(a) && cb_debug_knob("CUDABROT_AMD_NO_WIDE") == nullptr;
   const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
+  g_last_draw_kernel = base_variant == CB_KERNEL_SIMPLE ? 3 : (wide ? 2 : 1);
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
       return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));
@@ -457,6 +463,7 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
     if (rc) return rc;
   }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
+  g_last_draw_kernel = 1;
   return (int) wave(a, false, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -279,6 +279,10 @@ int cb_abi_version(void);
  * gate: the value of `name`, or NULL unless CUDABROT_AMD_DEBUG=1 is set too -- a stray variable in a user's
  * environment cannot change the path the product takes.  (The reference has no such knobs.) */
 const char *cb_debug_knob(const char *name);
+/* Which draw kernel the last cb_draw_buddhabrot* call of this process launched (the renderer's calls included):
+ * 0 none yet, 1 draw_wave_kernel (four waves per SIMD), 2 draw_wide_kernel (two waves per SIMD, runs beside the
+ * scatter), 3 the lock-step baseline.  The kernels give identical results; tests use this to know what they covered. */
+int cb_debug_last_draw_kernel(void);
 
 #ifdef __cplusplus
 }
