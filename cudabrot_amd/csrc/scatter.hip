@@ -45,6 +45,9 @@
 #endif
 // ... of the region sort while it reads its region / writes its image (few instructions, long waits: worth issuing
 // early), while it ranks (most of its vector and LDS instructions), and of the gather
+#ifndef CB_LEAN_BATCH
+#define CB_LEAN_BATCH 4  // 16-byte loads a thread of the lean region sort keeps in flight
+#endif
 #ifndef CB_SORT_PRIO_IO
 #define CB_SORT_PRIO_IO 3   // (swept beside the wide draw kernel's 2 / 1, tools/gpu_wide_prio.sh: -5..7 % per step against 0)
 #endif
@@ -312,8 +315,10 @@ __device__ __forceinline__ uint32_t sort_word(uint32_t e, uint32_t k0, const Bin
 // kChunked (BinLayout::chunked): the region is a list of at most kRegionChunks chunks of the stream (region_start:
 // first entry of chunk_list, region_count: chunks) instead of a stretch of it; its image goes to sorted[r * 32768]
 // and region_count[r] becomes its number of entries, which is what the gather reads.
-template <bool kPlain, bool kFewTiles, bool kChunked = false>
-__global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b) {
+// kLean: the instance for the FULL regions of a plain stream on a 16-byte boundary (see below); the other instance of
+// such a launch then takes what is left (a wave's last, partial region).
+template <bool kPlain, bool kFewTiles, bool kChunked = false, bool kLean = false>
+__global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLayout b, uint32_t skip_lean) {
   constexpr uint32_t kCntReplicas = SortLds<kFewTiles>::kReplicas, kCntStride = SortLds<kFewTiles>::kStride;
   constexpr uint32_t kDummyKey = kCntStride - 16u;  // the counter behind a replica's real ones
   // Beside the two-waves-per-SIMD draw kernel (draw_wide.hip) these waves share their SIMDs with draw waves that
@@ -352,6 +357,84 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   __syncthreads();
   if (kChunked) n = chunks[kRegionChunks].x;
 
+  // A FULL region of a plain stream on a 16-byte boundary (ten of a wave's eleven at C3): no masks, no dummy key, and
+  // every entry carries the LDS byte address of its tile's counter instead of the key, so that the ranking pass is
+  // two vector instructions per entry.  11 vector instructions per entry instead of 25: alone on the GPU the sort is
+  // memory-bound either way, beside the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
+  const bool lean_region = kPlain && !kChunked && n == kRegionEntries && (start & 7ull) == 0ull;
+  if (!kLean && skip_lean != 0u && lean_region) continue;  // (the lean instance's)
+  if (kLean && !lean_region) continue;
+  if constexpr (kLean) {
+    const uint32_t cnt_byte = (uint32_t) ((threadIdx.x % kCntReplicas) * kCntStride * sizeof(uint32_t));
+    char *const lds_bytes = reinterpret_cast<char *>(lds);
+    const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+    const uint32_t tiles_x = b.tiles_x;
+    uint32_t e[kSortPerThread];
+    constexpr uint32_t kBatch = CB_LEAN_BATCH;  // 16-byte loads in flight per thread
+#pragma unroll
+    for (uint32_t part = 0; part < kSortPerThread / 4u / kBatch; ++part) {
+      uint4 v[kBatch];
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j) v[j] = src4[(part * kBatch + j) * kSortThreads + threadIdx.x];
+#pragma unroll
+      for (uint32_t j = 0; j < kBatch; ++j) {
+        asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
+        const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+          const uint32_t w = words[q];
+          const uint32_t key = __umul24(w >> (16 + kTileShift), tiles_x) + ((w & 0xffffu) >> kTileShift) - k0;
+          const uint32_t off = ((w >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) | (w & (kTileSize - 1u));
+          const uint32_t addr = cnt_byte + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
+          lds_inc(reinterpret_cast<uint32_t *>(lds_bytes + addr));
+          uint32_t packed = (addr << 16) | off;
+          asm volatile("" : "+v"(packed));  // formed HERE (else address and offset are kept apart until the ranking pass)
+          e[4u * (part * kBatch + j) + q] = packed;
+        }
+      }
+      asm volatile("" ::: "memory");  // (one batch after the other: the registers of a batch are free for the next)
+    }
+    __syncthreads();
+    {  // 2. where each tile's run starts (as below)
+      const bool has_key = threadIdx.x < kDummyKey;
+      uint32_t c[kCntReplicas], sum = 0;
+#pragma unroll
+      for (uint32_t k = 0; k < kCntReplicas; ++k) {
+        c[k] = has_key ? lds[k * kCntStride + threadIdx.x] : 0u;
+        sum += c[k];
+      }
+      uint32_t total = 0;
+      uint32_t first = block_exclusive_scan(sum, wave_totals, &total);
+      __syncthreads();
+      if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
+#pragma unroll
+      for (uint32_t k = 0; k < kCntReplicas; ++k) {
+        if (has_key) lds[k * kCntStride + threadIdx.x] = first;
+        first += c[k];
+      }
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(CB_SORT_PRIO_RANK);
+#pragma unroll
+    for (uint32_t g = 0; g < kSortPerThread / 8u; ++g) {  // 3. rank and place, eight entries' atomics in flight
+      uint32_t pos[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) {
+        pos[k] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(lds_bytes + (e[8u * g + k] >> 16)), 1u,
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; ++k) image[pos[k]] = (uint16_t) e[8u * g + k];
+      asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(CB_SORT_PRIO_IO);
+    {  // 4. the image leaves as one linear block
+      const uint4 *s4 = reinterpret_cast<const uint4 *>(image);
+      uint4 *d4 = reinterpret_cast<uint4 *>(b.sorted + start);
+      for (uint32_t i = threadIdx.x; i < kRegionEntries / 8u; i += kSortThreads) d4[i] = s4[i];
+    }
+  } else {
   // 1. the region's entries, once: e[k] = (key << 16) | in-tile offset, ~0 beyond the region; counts per tile.
   // Which thread takes which entry does not matter: 16-byte loads from the 16-byte boundary below the region
   // (a region of a group starts anywhere; `head` entries before it are masked, and regions that may start
@@ -475,6 +558,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     for (uint32_t i = lo + threadIdx.x; i < hi; i += kSortThreads) dst[i] = image[i];
   }
   if (kChunked && threadIdx.x == 0) b.region_count[r] = n;  // from chunks to entries (every region is sorted once)
+  }  // (not the lean instance)
   }  // regions of this workgroup
 }
 
@@ -989,19 +1073,28 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   const bool plain = b.n_planes == 1u && b.e_row_shift == 16u && b.e_col_mask == 0xffffu && b.e_row_mask == 0xffffu &&
                      b.e_chan_mask == 0u;
   const bool few = b.n_tiles <= kFewTilesMax;
+  uint32_t skip_lean = 0u;
   const auto launch_sort = [&](auto kernel, size_t lds_bytes) -> hipError_t {
     // per call: the attribute belongs to the current device
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);  // ~74 KiB of the 160 per CU
     if (e != hipSuccess) return e;
     const uint32_t grid = b.max_regions < kSortGrid ? b.max_regions : kSortGrid;
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSortThreads), lds_bytes, stream, b);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSortThreads), lds_bytes, stream, b, skip_lean);
     return hipSuccess;
   };
   hipError_t se;
   if (b.chunked) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, false, true>, SortLds<false>::kBytes);
+  } else if (plain && !b.two_level) {
+    // the full regions first (lean instance: 11 vector instructions per entry), then the waves' last, partial ones
+    se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes)
+             : launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes);
+    if (se != hipSuccess) return se;
+    skip_lean = 1u;
+    se = few ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
+             : launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes);
   } else if (few) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, true>, SortLds<true>::kBytes);
