@@ -1087,6 +1087,7 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   if (b.chunked) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, false, true>, SortLds<false>::kBytes);
+#ifndef CB_NO_LEAN_SORT
   } else if (plain && !b.two_level) {
     // the full regions first (lean instance: 11 vector instructions per entry), then the waves' last, partial ones
     se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes)
@@ -1095,6 +1096,7 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     skip_lean = 1u;
     se = few ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
              : launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes);
+#endif
   } else if (few) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, true>, SortLds<true>::kBytes);
