@@ -719,92 +719,121 @@ __device__ __forceinline__ void long_refill4(Orbit (&o)[kSlots], double (&seen_r
       : "vcc", "scc", "memory");
 }
 
-// long_retire (draw_wave.hip) with this kernel's Q2 ring (320 entries, q2_ci 2560 bytes on) and its iteration
-// bookkeeping: the lanes that push add what the stages have COUNTED for their orbit so far -- cntk - l_rem with
-// cntk = max_iter + kChunk: HEAD + MID + every LONG chunk incl. this one -- to `counted`.  The reference executes
-// k + 1 iterations for an orbit that escapes at index k, and exactly that many replay steps record it later
-// (cudabrot.cu:336,363); so over all pushed orbits  counted - replay steps  is what the sparse chunks counted beyond
-// the escapes, and the kernel reports iterate_steps - (counted - replay steps): exact without any lane ever knowing
-// the escape index of an orbit.
-#define CBW_RETIRE_ESCAPED                                 \
-      "s_mov_b64 %[save], exec\n\t"  \
-      "s_mov_b64 %[push], 0\n\t"  \
-      "s_mov_b64 %[ended], 0\n\t"  \
-      "s_mov_b64 %[per], 0\n\t"  \
-      "s_cmp_eq_u64 %[ran], 0\n\t"  /* nothing ran in this slot: nothing to retire */ \
-      "s_cbranch_scc1 3f\n\t"  \
-      "s_mov_b64 exec, %[esc]\n\t"  \
-      "s_cbranch_execz 1f\n\t"  \
-      "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem]\n\t"  \
-      "v_sub_u32 %[t], %[cntk], %[lrem]\n\t"  \
-      "v_mov_b32 %[lrem], 0\n\t"  \
-      "s_mov_b64 %[push], vcc\n\t"  \
-      "s_mov_b64 exec, vcc\n\t"  \
-      "s_cbranch_execz 1f\n\t"  \
-      "v_add_u32 %[acc], %[acc], %[t]\n\t"  \
-      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"  \
-      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"  \
-      "v_add_u32 %[slot], %[tail2], %[slot]\n\t"  \
-      "v_subrev_u32 %[t], 320, %[slot]\n\t"  \
-      "v_min_u32 %[slot], %[slot], %[t]\n\t"  \
-      "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"  \
-      "ds_write_b64 %[slot], %[cr]\n\t"  \
-      "ds_write_b64 %[slot], %[ci] offset:2560\n\t"  \
-      "1:\n\t"  \
-      "s_andn2_b64 exec, %[ran], %[esc]\n\t"  \
-      "s_cbranch_execz 3f\n\t"
-#define CBW_RETIRE_SURVIVORS                               \
-      "v_subrev_u32 %[lrem], " CB_CHUNK_S ", %[lrem]\n\t" \
-      "v_cmp_eq_u32_e64 %[ended], 0, %[lrem]\n\t"        \
-      "s_cmp_eq_u32 %[chkf], 0\n\t"                      \
-      "s_cbranch_scc1 2f\n\t"                            \
-      "v_cmp_eq_u64_e32 vcc, %[r], %[sr]\n\t"            \
-      "s_mov_b64 %[per], vcc\n\t"                        \
-      "v_cmp_eq_u64_e32 vcc, %[i], %[si]\n\t"            \
-      "s_and_b64 %[per], %[per], vcc\n\t"                \
-      "s_andn2_b64 %[per], %[per], %[ended]\n\t"         \
-      "s_cmp_eq_u64 %[per], 0\n\t"                       \
-      "s_cbranch_scc1 2f\n\t"                            \
-      "s_mov_b64 exec, %[per]\n\t"                       \
-      "v_add_co_u32 %[klo], vcc, %[klo], %[lrem]\n\t"    \
-      "s_nop 1\n\t"                                      \
-      "v_addc_co_u32 %[khi], vcc, 0, %[khi], vcc\n\t"    \
-      "v_mov_b32 %[lrem], 0\n\t"                         \
-      "s_andn2_b64 exec, %[ran], %[esc]\n\t"             \
-      "2:\n\t"                                           \
-      "s_andn2_b64 exec, exec, %[per]\n\t"
-#define CBW_RETIRE_TAIL                                    \
-      "v_sub_u32 %[t], %[ls], %[lrem]\n\t"               \
-      "v_cvt_f32_u32 %[t], %[t]\n\t"                     \
-      "v_mul_f32 %[t], %[invl], %[t]\n\t"                \
-      "v_rndne_f32 %[t], %[t]\n\t"                       \
-      "v_and_b32 %[t], %[kmask], %[t]\n\t"               \
-      "v_cmpx_eq_u32_e32 vcc, 0, %[t]\n\t"               \
-      "v_mov_b64 %[sr], %[r]\n\t"                        \
-      "v_mov_b64 %[si], %[i]\n\t"                        \
-      "3:\n\t"                                           \
-      "s_mov_b64 exec, %[save]\n\t"                      \
-      "s_nop 4\n\t"
+// One slot's part of long_retire4 (K: the slot).  ran / esc: the lanes of the slot that ran the chunk / whose orbit
+// escaped in it.
+//   escaped lanes    l_rem = 0; those whose chunk lies at or above min_iter (l_rem <= accept_rem: all of them in this
+//                    kernel's launches, `bad` says otherwise) push c to Q2 and add cntk - l_rem to `counted`
+//   the others       l_rem -= kChunk; ended: reached max_iter (cudabrot.cu:339); periodic (chkf != 0 only): z is bit
+//                    for bit the saved point -- retired, the remaining iterations added to skip; else Brent's
+//                    schedule, refined (draw_wave.hip, long_retire): re-save z when the number of chunks done has no
+//                    set bit below its top two
+#define CBW_RETIRE_SLOT(K)                                                 \
+      "s_cmp_eq_u64 %[ran" #K "], 0\n\t"  /* nothing ran in this slot */ \
+      "s_cbranch_scc1 3" #K "f\n\t"                                        \
+      "s_mov_b64 exec, %[esc" #K "]\n\t"                                   \
+      "s_cbranch_execz 1" #K "f\n\t"                                       \
+      "v_cmp_ge_i32_e32 vcc, %[thr], %[lrem" #K "]\n\t"                    \
+      "v_sub_u32 %[t], %[cntk], %[lrem" #K "]\n\t"                         \
+      "v_mov_b32 %[lrem" #K "], 0\n\t"                                     \
+      "s_andn2_b64 %[m], exec, vcc\n\t"        /* escaped but not accepted: cannot happen */ \
+      "s_or_b64 %[bad], %[bad], %[m]\n\t"                                  \
+      "s_mov_b64 exec, vcc\n\t"                                            \
+      "s_cbranch_execz 1" #K "f\n\t"                                       \
+      "v_add_u32 %[acc], %[acc], %[t]\n\t"                                 \
+      "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"                         \
+      "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"                   \
+      "s_bcnt1_i32_b64 %[n], exec\n\t"                                     \
+      "v_add_u32 %[slot], %[tail2], %[slot]\n\t"                           \
+      "s_add_u32 %[pushed], %[pushed], %[n]\n\t"                           \
+      "v_subrev_u32 %[t], 320, %[slot]\n\t"                                \
+      "s_add_u32 %[tail2], %[tail2], %[n]\n\t"                             \
+      "v_min_u32 %[slot], %[slot], %[t]\n\t"                               \
+      "s_sub_u32 %[n], %[tail2], 320\n\t"                                  \
+      "v_lshl_add_u32 %[slot], %[slot], 3, %[q2]\n\t"                      \
+      "s_cmp_ge_u32 %[tail2], 320\n\t"                                     \
+      "ds_write_b64 %[slot], %[cr" #K "]\n\t"                              \
+      "s_cselect_b32 %[tail2], %[n], %[tail2]\n\t"                         \
+      "ds_write_b64 %[slot], %[ci" #K "] offset:2560\n\t"                  \
+      "1" #K ":\n\t"                                                       \
+      "s_andn2_b64 exec, %[ran" #K "], %[esc" #K "]\n\t"                   \
+      "s_cbranch_execz 3" #K "f\n\t"                                       \
+      "v_subrev_u32 %[lrem" #K "], " CB_CHUNK_S ", %[lrem" #K "]\n\t"      \
+      "v_sub_u32 %[t], %[ls], %[lrem" #K "]\n\t"      /* steps done, for the save schedule below */ \
+      "v_cmp_eq_u32_e64 %[m], 0, %[lrem" #K "]\n\t"   /* ended */         \
+      "v_cvt_f32_u32 %[t], %[t]\n\t"                                       \
+      "s_cmp_eq_u32 %[chkf], 0\n\t"                                        \
+      "s_cbranch_scc1 2" #K "f\n\t"                                        \
+      "v_cmp_eq_u64_e32 vcc, %[r" #K "], %[sr" #K "]\n\t"                  \
+      "v_cmp_eq_u64_e64 %[per], %[i" #K "], %[si" #K "]\n\t"               \
+      "v_mul_f32 %[t], %[invl], %[t]\n\t"                                  \
+      "s_bcnt1_i32_b64 %[n], %[m]\n\t"                                     \
+      "s_add_u32 %[never], %[never], %[n]\n\t"                             \
+      "s_and_b64 %[per], %[per], vcc\n\t"                                  \
+      "s_andn2_b64 %[per], %[per], %[m]\n\t"                               \
+      "s_cmp_eq_u64 %[per], 0\n\t"                                         \
+      "s_cbranch_scc1 4" #K "f\n\t"                                        \
+      "s_bcnt1_i32_b64 %[n], %[per]\n\t"                                   \
+      "s_add_u32 %[never], %[never], %[n]\n\t"                             \
+      "s_mov_b64 %[m], exec\n\t"                                           \
+      "s_mov_b64 exec, %[per]\n\t"                                         \
+      "v_add_co_u32 %[klo], vcc, %[klo], %[lrem" #K "]\n\t"                \
+      "v_mov_b32 %[lrem" #K "], 0\n\t"                                     \
+      "v_addc_co_u32 %[khi], vcc, 0, %[khi], vcc\n\t"                      \
+      "s_andn2_b64 exec, %[m], %[per]\n\t"                                 \
+      "s_branch 4" #K "f\n\t"                                              \
+      "2" #K ":\n\t"                                                       \
+      "v_mul_f32 %[t], %[invl], %[t]\n\t"                                  \
+      "s_bcnt1_i32_b64 %[n], %[m]\n\t"                                     \
+      "s_add_u32 %[never], %[never], %[n]\n\t"                             \
+      "4" #K ":\n\t"                                                       \
+      "v_rndne_f32 %[t], %[t]\n\t"                                         \
+      "v_and_b32 %[t], %[kmask], %[t]\n\t"                                 \
+      "v_cmpx_eq_u32_e32 vcc, 0, %[t]\n\t"                                 \
+      "v_mov_b64 %[sr" #K "], %[r" #K "]\n\t"                              \
+      "v_mov_b64 %[si" #K "], %[i" #K "]\n\t"                              \
+      "3" #K ":\n\t"
 
-__device__ __forceinline__ void long_retire(const Orbit &o, double &seen_r, double &seen_i, int &l_rem,
-                                            uint32_t &skip_lo, uint32_t &skip_hi, uint32_t &counted,
-                                            unsigned long long ran, unsigned long long esc, int accept_rem,
-                                            uint32_t long_steps, uint32_t counted_base, uint32_t check_periodic,
-                                            uint32_t q2_tail, uint32_t q2_lds, unsigned long long &push,
-                                            unsigned long long &ended, unsigned long long &periodic) {
-  static_assert(kQ2Cap == 320, "ring length and plane distance above (q2_ci 2560 bytes on)");
-  unsigned long long save;
-  uint32_t slot, t;
+// long_retire4: after a chunk, the four slots in one statement (draw_wave.hip's long_retire per slot, with this
+// kernel's Q2 ring -- 320 entries, q2_ci 2560 bytes on -- and its iteration bookkeeping).  The lanes that push add
+// what the stages have COUNTED for their orbit so far -- cntk - l_rem with cntk = max_iter + kChunk: HEAD + MID +
+// every LONG chunk incl. this one -- to `counted`.  The reference executes k + 1 iterations for an orbit that escapes
+// at index k, and exactly that many replay steps record it later (cudabrot.cu:336,363); so over all pushed orbits
+// counted - replay steps  is what the sparse chunks counted beyond the escapes, and the kernel reports
+// iterate_steps - (counted - replay steps): exact without any lane ever knowing the escape index of an orbit.
+// pushed / never: orbits pushed to Q2 / retired as never escaping (ended + periodic); bad: lanes that escaped in a
+// chunk below min_iter (none in the launches this kernel takes).
+__device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&seen_r)[kSlots], double (&seen_i)[kSlots],
+                                             int (&l_rem)[kSlots], uint32_t &skip_lo, uint32_t &skip_hi, uint32_t &counted,
+                                             const unsigned long long (&ran)[kSlots], const unsigned long long (&esc)[kSlots],
+                                             int accept_rem, uint32_t long_steps, uint32_t counted_base,
+                                             uint32_t check_periodic, uint32_t q2_tail, uint32_t q2_lds, uint32_t &pushed,
+                                             uint32_t &never, unsigned long long &bad) {
+  static_assert(kQ2Cap == 320 && kSlots == 4, "ring length, plane distance and the four slot blocks");
+  unsigned long long save, m, per;
+  uint32_t slot, t, n;
   const float inv_chunk = 1.0f / (float) kChunk;
   const uint32_t low_mantissa = (1u << (24 - kBrentBits)) - 1u;
-  asm volatile(CBW_RETIRE_ESCAPED CBW_RETIRE_SURVIVORS CBW_RETIRE_TAIL
-               : [sr] "+v"(seen_r), [si] "+v"(seen_i), [lrem] "+v"(l_rem), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi),
-                 [acc] "+v"(counted), [push] "=&s"(push), [ended] "=&s"(ended), [per] "=&s"(periodic),
-                 [save] "=&s"(save), [slot] "=&v"(slot), [t] "=&v"(t)
-               : [ran] "s"(ran), [esc] "s"(esc), [thr] "s"(accept_rem), [ls] "s"(long_steps), [tail2] "s"(q2_tail),
-                 [cntk] "s"(counted_base), [chkf] "s"(check_periodic), [invl] "s"(inv_chunk), [kmask] "s"(low_mantissa),
-                 [q2] "s"(q2_lds), [cr] "v"(o.cr), [ci] "v"(o.ci), [r] "v"(o.r), [i] "v"(o.i)
-               : "vcc", "scc", "memory");
+  q2_tail = __builtin_amdgcn_readfirstlane(q2_tail);
+  asm volatile(
+      "s_mov_b64 %[save], exec\n\t"
+      "s_mov_b32 %[pushed], 0\n\t"
+      "s_mov_b32 %[never], 0\n\t"
+      "s_mov_b64 %[bad], 0\n\t"
+      CBW_RETIRE_SLOT(0) CBW_RETIRE_SLOT(1) CBW_RETIRE_SLOT(2) CBW_RETIRE_SLOT(3)
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_nop 4\n\t"
+      : [sr0] "+v"(seen_r[0]), [si0] "+v"(seen_i[0]), [lrem0] "+v"(l_rem[0]), [sr1] "+v"(seen_r[1]), [si1] "+v"(seen_i[1]),
+        [lrem1] "+v"(l_rem[1]), [sr2] "+v"(seen_r[2]), [si2] "+v"(seen_i[2]), [lrem2] "+v"(l_rem[2]), [sr3] "+v"(seen_r[3]),
+        [si3] "+v"(seen_i[3]), [lrem3] "+v"(l_rem[3]), [klo] "+v"(skip_lo), [khi] "+v"(skip_hi), [acc] "+v"(counted),
+        [tail2] "+s"(q2_tail), [pushed] "=&s"(pushed), [never] "=&s"(never), [bad] "=&s"(bad), [save] "=&s"(save),
+        [m] "=&s"(m), [per] "=&s"(per), [n] "=&s"(n), [slot] "=&v"(slot), [t] "=&v"(t)
+      : [ran0] "s"(ran[0]), [esc0] "s"(esc[0]), [ran1] "s"(ran[1]), [esc1] "s"(esc[1]), [ran2] "s"(ran[2]),
+        [esc2] "s"(esc[2]), [ran3] "s"(ran[3]), [esc3] "s"(esc[3]), [thr] "s"(accept_rem), [ls] "s"(long_steps),
+        [cntk] "s"(counted_base), [chkf] "s"(check_periodic), [invl] "s"(inv_chunk), [kmask] "s"(low_mantissa),
+        [q2] "s"(q2_lds), [cr0] "v"(o[0].cr), [ci0] "v"(o[0].ci), [r0] "v"(o[0].r), [i0] "v"(o[0].i), [cr1] "v"(o[1].cr),
+        [ci1] "v"(o[1].ci), [r1] "v"(o[1].r), [i1] "v"(o[1].i), [cr2] "v"(o[2].cr), [ci2] "v"(o[2].ci), [r2] "v"(o[2].r),
+        [i2] "v"(o[2].i), [cr3] "v"(o[3].cr), [ci3] "v"(o[3].ci), [r3] "v"(o[3].r), [i3] "v"(o[3].i)
+      : "vcc", "scc", "memory");
 }
 
 // ---- REPLAY burst, software-pipelined: IterateAndRecord (cudabrot.cu:347-365) into the pixel stream -------------
@@ -1416,17 +1445,19 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       const uint32_t check_flag = (uint32_t) la->check_periodic;
       const int accept_rem = la->accept_rem;
       const uint32_t counted_base = (uint32_t) la->max_iter + (uint32_t) kChunk;
+      {
+        unsigned long long ran_u[kSlots], esc_u[kSlots], bad;
 #pragma unroll
-      for (int o = 0; o < kSlots; ++o) {
-        unsigned long long push = 0ull, ended = 0ull, periodic = 0ull;
-        const uint32_t q2_tail = __builtin_amdgcn_readfirstlane((uint32_t) q2_wrap(q2_head + q2_count));
-        long_retire(lo[o], seen_r[o], seen_i[o], l_rem[o], skip_lo, skip_hi, counted, uniform_u64(full_mask[o]),
-                    uniform_u64(esc[o]), accept_rem, long_steps_u, counted_base, check_flag, q2_tail, q2_lds, push,
-                    ended, periodic);
-        q2_count += __popcll(push);
-        if (q2_count > kQ2Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
-        if ((esc[o] & ~push) != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (cannot happen: every LONG escape is accepted)
-        n_never += (unsigned long long) (__popcll(ended) + __popcll(periodic));
+        for (int o = 0; o < kSlots; ++o) {
+          ran_u[o] = uniform_u64(full_mask[o]);
+          esc_u[o] = uniform_u64(esc[o]);
+        }
+        uint32_t pushed, never;
+        long_retire4(lo, seen_r, seen_i, l_rem, skip_lo, skip_hi, counted, ran_u, esc_u, accept_rem, long_steps_u,
+                     counted_base, check_flag, (uint32_t) q2_wrap(q2_head + q2_count), q2_lds, pushed, never, bad);
+        q2_count += (int) pushed;
+        if (q2_count > kQ2Cap || bad != 0ull) status |= CB_STATUS_QUEUE_OVERFLOW;  // (bad: cannot happen, every LONG escape is accepted)
+        n_never += never;
       }
       if (kTimed) t_long += __builtin_amdgcn_s_memtime() - t0;
     }
