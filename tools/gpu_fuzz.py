@@ -63,6 +63,18 @@ def trial(rng):
     t["windows"] = None
     if rng.random() < 0.25:                      # fused multi-channel launch: plane j == a run with window j
         t["windows"] = [(rng.choice([30, 100, 400, 2500]), rng.choice([0, 5, 20, 50, 300])) for _ in range(rng.randint(1, 4))]
+    if rng.random() < 0.35:
+        # a launch draw_wide_kernel takes (draw_wide.hip): whole workgroups of 512 subsequences, min_iter at the start
+        # of the LONG stage, one level, one channel, a carry buffer, a workspace (suggested or short: a full stream
+        # region makes the bursts add directly); tails of every length through max_iter
+        t["threads"] = rng.choice([512, 1024, 2048, 4096, 16384])
+        t["min_iter"] = 20
+        t["max_iter"] = rng.choice([21, 33, 64, 79, 80, 81, 100, 140, 257, 1000, 2000, 5000, 20000])
+        t["launch_samples"] = [rng.choice([30, 50, 64, 100, 150, 400]) for _ in range(rng.randint(1, 4))]
+        t["workspace"] = rng.choice(["suggested", "suggested", "short"])
+        t["carry"] = rng.choice(["drain_launch", "drain_flag"])
+        t["two_level"] = False
+        t["windows"] = None
     if t["max_iter"] >= 5000:   # keep the lock-step kernel's run time in hand
         t["threads"] = min(t["threads"], 4096)
     return t
@@ -197,6 +209,7 @@ def main():
     t_end = time.time() + seconds
     n = 0
     last_print = time.time()
+    wide_trials = [0]   # trials whose last product launch was draw_wide_kernel's
     while time.time() < t_end:
         if os.environ.get("HEAVY") == "1":
             t = heavy_trial(rng)
@@ -230,6 +243,8 @@ def main():
             else:
                 want, wc = render(t, cb.CB_KERNEL_SIMPLE)
                 got, gc = render(t, cb.CB_KERNEL_DEFAULT)
+                if cb.lib.cb_debug_last_draw_kernel() == 2:
+                    wide_trials[0] += 1
         except cb.CudabrotError as e:
             print("trial %d: error %s\n  %r" % (n, e, t), flush=True)
             return 1
@@ -246,9 +261,9 @@ def main():
                 t["w"], t["h"], t["max_iter"], t["threads"], t["launch_samples"], t["workspace"], t["carry"],
                 t["two_level"] or (t["w"] + 127) // 128 * ((t["h"] + 127) // 128) > 4096), flush=True)
         if time.time() - last_print > 30:
-            print("%d trials identical so far" % n, flush=True)
+            print("%d trials identical so far (%d through draw_wide_kernel)" % (n, wide_trials[0]), flush=True)
             last_print = time.time()
-    print("gpu_fuzz: %d trials, histograms and counters identical (seed %d)" % (n, seed))
+    print("gpu_fuzz: %d trials (%d through draw_wide_kernel), histograms and counters identical (seed %d)" % (n, wide_trials[0], seed))
     return 0
 
 
