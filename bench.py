@@ -596,6 +596,11 @@ def main():
                 "frac_alone": round(tflops * avg_ms / (sum(seq_draw_ms) / len(seq_draw_ms)) / PEAK_FP64_VECTOR_TFLOPS, 4)
                 if seq_draw_ms else None,
                 "algorithmic_flops_per_launch": iters_per_launch * FLOPS_PER_ITERATION,
+                # the same flops over the WHOLE step (draw and scatter, drain included): the figure that compares across
+                # rounds -- since round 3 the draw launch shares the GPU with the scatter of the launch before it, so its
+                # own duration (avg_launch_ms) is longer although the step is shorter
+                "step_frac": round(iters_per_launch * FLOPS_PER_ITERATION / (elapsed / args.steps) / 1e12
+                                   / PEAK_FP64_VECTOR_TFLOPS, 4),
                 "traffic": traffic["draw"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "note": "no MFMA: the path has no contraction; 10 ALGORITHMIC flops per z<-z^2+c iteration (the reference's "
@@ -608,8 +613,10 @@ def main():
                         "ceiling-bounded utilisation.  The bounded one is `valu_busy`: SQ_INSTS_VALU of the committed rocprofv3 "
                         "counter pass (valu_busy_source) x 4 cycles over the SIMD-cycles of the same profiled dispatch, at the "
                         "2.4 GHz spec clock and at the clock the same counters give.  avg_launch_ms is measured in the pipelined "
-                        "timed region, where the scatter kernels of the previous launch share the GPU (alone_ms / frac_alone: "
-                        "the same launch with nothing beside it, before the clock)",
+                        "timed region, where the scatter kernels of the previous launch run on the same CUs at the same time (since "
+                        "round 3 by design: draw_wide_kernel fills the fp64 pipe from two waves per SIMD and leaves the rest "
+                        "of every CU to the scatter, DESIGN.md 4.1b) -- alone_ms / frac_alone: the same launch with nothing "
+                        "beside it, before the clock; step_frac: the same flops over the whole step",
             },
             "roofline_scatter": {
                 "bound": "hbm",

@@ -39,8 +39,15 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
                     agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
                     pmc[k]["_dispatch"] = {x: r[x] for x in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                                              "VGPR_Count", "SGPR_Count")}
+        # dispatches of the draw kernel in this pass = launches of the pipeline; a kernel that is dispatched several
+        # times per launch (the region sort: its lean instance for the full regions, then the rest) counts per
+        # launch as the SUM of its consecutive dispatches
+        n_launches = max([len(v) for (k, c), v in agg.items() if k.startswith("draw_")] or [0])
         for (k, c), v in agg.items():
-            # the MEDIAN dispatch: a bench run also issues drain launches (no samples, little traffic)
+            per = len(v) // n_launches if n_launches and len(v) % n_launches == 0 and len(v) > n_launches else 1
+            if per > 1:
+                v = [sum(v[i:i + per]) for i in range(0, len(v), per)]
+            # the MEDIAN launch: a bench run also issues drain launches (no samples, little traffic)
             med = sorted(v)[len(v) // 2]
             pmc[k][c] = {"mean_per_dispatch": med, "statistic": "median over dispatches", "all": v,
                          "dispatches": len(v), "pass": os.path.basename(d)}
