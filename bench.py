@@ -280,7 +280,7 @@ class Job:
             cb.flush_scatter(self.dims, self.hist.data_ptr(), self.threads, self.workspaces[k].data_ptr(), self.ws_bytes,
                              self.flush_stream if stream is None else stream)
 
-    def step(self, samples=None, ev_draw=None, ev_flush=None):
+    def step(self, samples=None, ev_draw=None, ev_flush=None, variant=None):
         """One launch of the dominant kernel (sample -> iterate -> replay, cudabrot.cu:379-414) on the draw
         stream and its scatter on the flush stream."""
         samples = self.samples if samples is None else samples
@@ -290,7 +290,7 @@ class Job:
             self.flush_pending[k] = False
         if ev_draw:
             ev_draw[0].record(self.draw_stream_t)
-        self.draw(samples, k)
+        self.draw(samples, k, variant=variant)
         if ev_draw:
             ev_draw[1].record(self.draw_stream_t)
         if self.ws_bytes:
@@ -403,6 +403,9 @@ def main():
                     help="skip the short before-the-clock legs of C4, C2 and C5 (`other_configs`)")
     ap.add_argument("--direct-atomics", action="store_true",
                     help="no scatter workspace: every increment is a device-scope atomic (A/B baseline)")
+    ap.add_argument("--drain-in-last-step", action="store_true",
+                    help="A/B: the last timed launch completes its own in-flight orbits (CB_KERNEL_FLAG_DRAIN) instead of "
+                         "a drain launch behind it")
     ap.add_argument("--single-stream", action="store_true",
                     help="A/B: issue the scatter of launch k behind draw k on the same stream instead of on a second "
                          "stream beside draw k+1 (measured: 2 % slower)")
@@ -490,10 +493,12 @@ def main():
     dev_ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     fence()
     t0 = time.perf_counter()
-    for a, b, c, d in ev:
-        job.step(ev_draw=(a, b), ev_flush=(c, d))
+    for n_ev, (a, b, c, d) in enumerate(ev):
+        last = args.drain_in_last_step and n_ev == len(ev) - 1
+        job.step(ev_draw=(a, b), ev_flush=(c, d), variant=(cb.CB_KERNEL_DEFAULT | cb.CB_KERNEL_FLAG_DRAIN) if last else None)
     dev_ev[0].record(job.draw_stream_t)
-    job.step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
+    if not args.drain_in_last_step:
+        job.step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
     dev_ev[1].record(job.draw_stream_t)
