@@ -7,10 +7,10 @@ import re
 import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
-draws = [(s, e) for s, e, n in ev if "draw_wave_kernel" in n]
+draws = [(s, e) for s, e, n in ev if ("draw_wave_kernel" in n or "draw_wide_kernel" in n)]
 stat = collections.defaultdict(lambda: [0, 0, 0.0, 0.0])
 for s, e, n in ev:
-    if "draw_wave_kernel" in n:
+    if ("draw_wave_kernel" in n or "draw_wide_kernel" in n):
         continue
     m = re.search(r"(\w+_kernel\w*|__amd_\w+)", n)
     short = m.group(1) if m else n[:40]
