@@ -1176,6 +1176,10 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   const uint32_t wave_slot = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));  // HW_REG_HW_ID bits 3:0
   uint32_t long_chunks = 0;
   unsigned long long t_head = 0, t_mid = 0, t_long = 0, t_replay = 0;
+#ifdef CB_WIDE_PROBE  // (tools/wide_stage_probe.py: units of work per stage beside the stage clocks)
+  unsigned long long probe_chunks = 0, probe_lane_chunks = 0, probe_replay_steps = 0, probe_bursts = 0;
+  unsigned long long probe_lanes_at_start = 0, probe_lanes_at_end = 0;
+#endif
   const unsigned long long t_start = kTimed ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt_start = kTimed ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const uint32_t q0_lds = __builtin_amdgcn_readfirstlane(
@@ -1317,6 +1321,9 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       // burst add to the histogram directly, so the result never depends on the workspace size.
       const uint32_t direct = (region_fill + 64u * kReplayBurst <= region_cap) ? 0u : 1u;
       uint32_t steps = 0, hits = 0, popped;
+#ifdef CB_WIDE_PROBE
+      const uint32_t clock_before = replay_clock;
+#endif
       popped = replay_stage<kPow2>(do_replay ? 1u : 0u, pact, (uint32_t) q2_head, (uint32_t) q2_count, q2_lds,
                                    draining ? 1u : (uint32_t) kReplayMin, kReplayBurst, direct, po, p_start, region,
                                    region_fill, replay_clock, steps, hits);
@@ -1325,6 +1332,14 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       n_recorded += popped;
       n_replay += steps;
       n_incr += hits;
+#ifdef CB_WIDE_PROBE
+      if (replay_clock != clock_before) {
+        probe_replay_steps += replay_clock - clock_before;
+        ++probe_bursts;
+        probe_lanes_at_start += (uint32_t) n_replaying + popped;
+        probe_lanes_at_end += (uint32_t) __popcll(pact);
+      }
+#endif
       if (do_replay && __ballot(lane_in(pact) && (replay_clock - p_start) > (uint32_t) max_iter) != 0ull) {
         // cannot happen: the orbit escaped within max_iter steps in an earlier stage
         status |= CB_STATUS_REPLAY_RUNAWAY;
@@ -1429,6 +1444,11 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       iterate_chunk4(any_full != 0ull ? 1u : 0u, full_mask, lo, esc, doubt, la->sparse_threshold);
       n_iterate += (unsigned long long) kChunk * (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]) +
                                                                        __popcll(full_mask[2]) + __popcll(full_mask[3]));
+#ifdef CB_WIDE_PROBE
+      probe_chunks += any_full != 0ull ? 1u : 0u;
+      probe_lane_chunks += (unsigned long long) (__popcll(full_mask[0]) + __popcll(full_mask[1]) + __popcll(full_mask[2]) +
+                                                 __popcll(full_mask[3]));
+#endif
       if (doubt != 0ull) {  // a sample with |c| next to 2 somewhere in the wave: decided exactly, slot by slot
         const double kt = la->sparse_threshold;
 #pragma unroll
@@ -1541,11 +1561,21 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       __hip_atomic_fetch_add(c + 11, t_long, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(c + 12, t_replay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(c + 13, t_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CB_WIDE_PROBE
+      (void) rt_start;
+      __hip_atomic_fetch_add(c + 14, probe_chunks | (probe_lane_chunks << 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(c + 15, probe_replay_steps | (probe_bursts << 36), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
       __hip_atomic_fetch_max(c + 14, ~rt_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_max(c + 15, rt_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       // (the MID stage's share of cycles_head, in the slot draw_wave_kernel uses for the waves' lifetimes)
+#ifdef CB_WIDE_PROBE
+      __hip_atomic_fetch_add(c + 16, probe_lanes_at_start | (probe_lanes_at_end << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       __hip_atomic_fetch_add(c + 16, t_mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
   }
 }
