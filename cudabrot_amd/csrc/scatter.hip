@@ -45,6 +45,9 @@
 #endif
 // ... of the region sort while it reads its region / writes its image (few instructions, long waits: worth issuing
 // early), while it ranks (most of its vector and LDS instructions), and of the gather
+#ifndef CB_GATHER_SKIP_BLOCKS
+#define CB_GATHER_SKIP_BLOCKS 1
+#endif
 #ifndef CB_LEAN_BATCH
 #define CB_LEAN_BATCH 4  // 16-byte loads a thread of the lean region sort keeps in flight
 #endif
@@ -122,6 +125,36 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *w
     all += wt;
   }
   *total = all;
+  return before + inc - v;
+}
+
+// The same for the region sort, whose 1024 threads run it once per region beside the draw kernel, where every vector
+// instruction counts: the wave's scan with DPP adds (row shifts, then the two row broadcasts: 6 instructions instead of
+// 6 LDS shuffles with their address arithmetic), and the 16 wave totals summed by each wave for itself, one per lane
+// (instead of 16 reads, compares and selects in every thread).  blockDim.x == 1024; no total.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  // v_add with a DPP operand: lanes without a source (first lanes of a row; rows a broadcast does not reach) add 0
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ uint32_t sort_exclusive_scan(uint32_t v, uint32_t *wave_totals) {
+  const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+  const uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63u) wave_totals[wid] = inc;
+  __syncthreads();
+  uint32_t wt = wave_totals[lane & 15u];
+  wt = (lane < wid) ? wt : 0u;  // (wid <= 15: lanes of the first row only)
+  // the sum of the first row, in its last lane
+  wt += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wt, 0x111, 0x1, 0xf, false);
+  wt += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wt, 0x112, 0x1, 0xf, false);
+  wt += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wt, 0x114, 0x1, 0xf, false);
+  wt += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wt, 0x118, 0x1, 0xf, false);
+  const uint32_t before = (uint32_t) __builtin_amdgcn_readlane((int) wt, 15);
   return before + inc - v;
 }
 
@@ -358,19 +391,27 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   if (kChunked) n = chunks[kRegionChunks].x;
 
   // A FULL region of a plain stream on a 16-byte boundary (ten of a wave's eleven at C3): no masks, no dummy key, and
-  // every entry carries the LDS byte address of its tile's counter instead of the key, so that the ranking pass is
-  // two vector instructions per entry.  11 vector instructions per entry instead of 25: alone on the GPU the sort is
-  // memory-bound either way, beside the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
+  // every entry carries the LDS byte address of its tile's counter instead of the key, the counters count bytes of the
+  // image, so that the ranking pass is ONE vector instruction per entry (the address out of the packed word).  10
+  // vector instructions per entry all told instead of 36: alone on the GPU the sort is memory-bound either way, beside
+  // the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
   const bool lean_region = kPlain && !kChunked && n == kRegionEntries && (start & 7ull) == 0ull;
   if (!kLean && skip_lean != 0u && lean_region) continue;  // (the lean instance's)
   if (kLean && !lean_region) continue;
   if constexpr (kLean) {
-    const uint32_t cnt_byte = (uint32_t) ((threadIdx.x % kCntReplicas) * kCntStride * sizeof(uint32_t));
-    char *const lds_bytes = reinterpret_cast<char *>(lds);
+    // LDS byte addresses as integers (the counters of this lane's replica, less the group's first key; the image), so
+    // that an entry's counter is ONE shift-and-add away from its key and the image takes positions as they are
+    typedef __attribute__((address_space(3))) uint32_t *LdsWord;
+    typedef __attribute__((address_space(3))) uint16_t *LdsHalf;
+    const uint32_t lds0 = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(lds));  // (a flat LDS address: the offset is its low word)
+    const uint32_t cnt_at = lds0 + (uint32_t) ((threadIdx.x % kCntReplicas) * kCntStride * sizeof(uint32_t)) - (k0 << 2);
+    const uint32_t image_at = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(image));
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     const uint32_t tiles_x = b.tiles_x;
     uint32_t e[kSortPerThread];
     constexpr uint32_t kBatch = CB_LEAN_BATCH;  // 16-byte loads in flight per thread
+    // 1. the entries, once: e = counter address << 16 | in-tile offset (7 vector instructions per entry); the counters
+    //    count BYTES of the image (2 per entry), so that the ranking below gets an entry's place as an address
 #pragma unroll
     for (uint32_t part = 0; part < kSortPerThread / 4u / kBatch; ++part) {
       uint4 v[kBatch];
@@ -382,12 +423,14 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
         const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
-          const uint32_t w = words[q];
-          const uint32_t key = __umul24(w >> (16 + kTileShift), tiles_x) + ((w & 0xffffu) >> kTileShift) - k0;
-          const uint32_t off = ((w >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) | (w & (kTileSize - 1u));
-          const uint32_t addr = cnt_byte + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
-          lds_inc(reinterpret_cast<uint32_t *>(lds_bytes + addr));
-          uint32_t packed = (addr << 16) | off;
+          const uint32_t w = words[q];  // row << 16 | col, col < 16384 (the host's condition for this instance)
+          const uint32_t key = __umul24(w >> (16 + kTileShift), tiles_x) + __builtin_amdgcn_ubfe(w, kTileShift, 16 - kTileShift);
+          const uint32_t addr = cnt_at + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
+          __hip_atomic_fetch_add((LdsWord) (uintptr_t) addr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // bits 7..13 from the row, the rest as it is: bits 0..6 are the column's, 14 and 15 are 0, and what lies
+          // above is cut off by the byte select that joins address and offset
+          const uint32_t off = ((w >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) | (w & ~((kTileSize - 1u) << kTileShift));
+          uint32_t packed = __builtin_amdgcn_perm(addr, off, 0x05040100u);  // addr << 16 | off & 0xffff
           asm volatile("" : "+v"(packed));  // formed HERE (else address and offset are kept apart until the ranking pass)
           e[4u * (part * kBatch + j) + q] = packed;
         }
@@ -395,7 +438,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
       asm volatile("" ::: "memory");  // (one batch after the other: the registers of a batch are free for the next)
     }
     __syncthreads();
-    {  // 2. where each tile's run starts (as below)
+    {  // 2. where each tile's run starts (byte positions; as below)
       const bool has_key = threadIdx.x < kDummyKey;
       uint32_t c[kCntReplicas], sum = 0;
 #pragma unroll
@@ -403,13 +446,12 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
         c[k] = has_key ? lds[k * kCntStride + threadIdx.x] : 0u;
         sum += c[k];
       }
-      uint32_t total = 0;
-      uint32_t first = block_exclusive_scan(sum, wave_totals, &total);
+      uint32_t first = sort_exclusive_scan(sum, wave_totals);
       __syncthreads();
-      if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
+      if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) (first >> 1);
 #pragma unroll
       for (uint32_t k = 0; k < kCntReplicas; ++k) {
-        if (has_key) lds[k * kCntStride + threadIdx.x] = first;
+        if (has_key) lds[k * kCntStride + threadIdx.x] = image_at + first;
         first += c[k];
       }
     }
@@ -420,11 +462,11 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
       uint32_t pos[8];
 #pragma unroll
       for (uint32_t k = 0; k < 8u; ++k) {
-        pos[k] = __hip_atomic_fetch_add(reinterpret_cast<uint32_t *>(lds_bytes + (e[8u * g + k] >> 16)), 1u,
+        pos[k] = __hip_atomic_fetch_add((LdsWord) (uintptr_t) (e[8u * g + k] >> 16), 2u,
                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 8u; ++k) image[pos[k]] = (uint16_t) e[8u * g + k];
+      for (uint32_t k = 0; k < 8u; ++k) *((LdsHalf) (uintptr_t) pos[k]) = (uint16_t) e[8u * g + k];
       asm volatile("" ::: "memory");
     }
     __syncthreads();
@@ -521,8 +563,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
       c[k] = has_key ? lds[k * kCntStride + threadIdx.x] : 0u;
       sum += c[k];
     }
-    uint32_t total = 0;
-    uint32_t first = block_exclusive_scan(sum, wave_totals, &total);
+    uint32_t first = sort_exclusive_scan(sum, wave_totals);
     __syncthreads();  // every count has been read
     if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) first;
 #pragma unroll
@@ -641,10 +682,21 @@ __global__ void __launch_bounds__(kAccThreads) bin_gather_accumulate_kernel(BinL
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
+          // (a block of eight that no lane of the wave has is skipped: runs average 32 entries behind their lead-in,
+          // so most rounds end after one or two of their four blocks -- beside the draw kernel the gather's vector
+          // instructions are what it costs)
+          const uint32_t i0 = at + 8u * j;
+          if (CB_GATHER_SKIP_BLOCKS && __ballot(i0 < len) == 0ull) break;
           const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+          // a block that lies inside the run in every lane (the runs of a hot tile are long, and alike): no tests
+          if (CB_GATHER_SKIP_BLOCKS && __ballot(i0 < lead || i0 + 8u > len) == 0ull) {
+#pragma unroll
+            for (uint32_t q = 0; q < 8; ++q) lds_inc(&tile[(words[q >> 1] >> ((q & 1u) * 16u)) & 0xffffu]);
+            continue;
+          }
 #pragma unroll
           for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t i = at + 8u * j + q;
+            const uint32_t i = i0 + q;
             if (i >= lead && i < len) lds_inc(&tile[(words[q >> 1] >> ((q & 1u) * 16u)) & 0xffffu]);
           }
         }
@@ -1088,8 +1140,8 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
                : launch_sort(bin_region_sort_kernel<false, false, true>, SortLds<false>::kBytes);
 #ifndef CB_NO_LEAN_SORT
-  } else if (plain && !b.two_level) {
-    // the full regions first (lean instance: 11 vector instructions per entry), then the waves' last, partial ones
+  } else if (plain && !b.two_level && b.tiles_x <= 128u) {  // (columns below 16384: the lean instance's word)
+    // the full regions first (lean instance: 10 vector instructions per entry), then the waves' last, partial ones
     se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes)
              : launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes);
     if (se != hipSuccess) return se;
