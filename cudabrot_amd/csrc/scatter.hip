@@ -37,6 +37,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 // priority of the sort / gather waves (0..3; tools/gpu_wide_prio.sh sweeps it against draw_wide.hip's CB_WIDE_PRIO_*)
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   // image, so that the ranking pass is ONE vector instruction per entry (the address out of the packed word).  10
   // vector instructions per entry all told instead of 36: alone on the GPU the sort is memory-bound either way, beside
   // the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
-  const bool lean_region = kPlain && !kChunked && n == kRegionEntries && (start & 7ull) == 0ull;
+  const bool lean_region = kPlain && !kChunked && n != 0u && (start & 7ull) == 0ull;
   if (!kLean && skip_lean != 0u && lean_region) continue;  // (the lean instance's)
   if (kLean && !lean_region) continue;
   if constexpr (kLean) {
@@ -408,24 +410,37 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     const uint32_t image_at = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(image));
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     const uint32_t tiles_x = b.tiles_x;
-    uint32_t e[kSortPerThread];
     constexpr uint32_t kBatch = CB_LEAN_BATCH;  // 16-byte loads in flight per thread
+    // kMasked: a region that is not full (a wave's last): loads clamped to the region, the slots beyond it count into the
+    // replica's dummy counter and are not placed -- two or three more instructions per entry, on a tenth of them
+    const auto sort_region = [&](auto masked) {
+    constexpr bool kMasked = decltype(masked)::value;
+    const uint32_t dummy_at = lds0 + (uint32_t) (((threadIdx.x % kCntReplicas) * kCntStride + kDummyKey) * sizeof(uint32_t));
+    const uint32_t last4 = (n - 1u) >> 2;
+    const uint32_t slot0 = 4u * threadIdx.x;  // this thread's slots: 4096 G + slot0 + q, G = 0..7
+    uint32_t e[kSortPerThread];
     // 1. the entries, once: e = counter address << 16 | in-tile offset (7 vector instructions per entry); the counters
     //    count BYTES of the image (2 per entry), so that the ranking below gets an entry's place as an address
 #pragma unroll
     for (uint32_t part = 0; part < kSortPerThread / 4u / kBatch; ++part) {
       uint4 v[kBatch];
 #pragma unroll
-      for (uint32_t j = 0; j < kBatch; ++j) v[j] = src4[(part * kBatch + j) * kSortThreads + threadIdx.x];
+      for (uint32_t j = 0; j < kBatch; ++j) {
+        const uint32_t i4 = (part * kBatch + j) * kSortThreads + threadIdx.x;
+        v[j] = src4[kMasked ? (i4 < last4 ? i4 : last4) : i4];
+      }
 #pragma unroll
       for (uint32_t j = 0; j < kBatch; ++j) {
+        // (the slots 4096 G .. 4096 G + 4095 of group G = part * kBatch + j: none inside the region -- nothing to count)
+        if (kMasked && (part * kBatch + j) * 4u * kSortThreads >= n) break;
         asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
         const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
           const uint32_t w = words[q];  // row << 16 | col, col < 16384 (the host's condition for this instance)
           const uint32_t key = __umul24(w >> (16 + kTileShift), tiles_x) + __builtin_amdgcn_ubfe(w, kTileShift, 16 - kTileShift);
-          const uint32_t addr = cnt_at + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
+          uint32_t addr = cnt_at + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
+          if (kMasked && !((part * kBatch + j) * 4u * kSortThreads + q + slot0 < n)) addr = dummy_at;
           __hip_atomic_fetch_add((LdsWord) (uintptr_t) addr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           // bits 7..13 from the row, the rest as it is: bits 0..6 are the column's, 14 and 15 are 0, and what lies
           // above is cut off by the byte select that joins address and offset
@@ -459,14 +474,21 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     __builtin_amdgcn_s_setprio(CB_SORT_PRIO_RANK);
 #pragma unroll
     for (uint32_t g = 0; g < kSortPerThread / 8u; ++g) {  // 3. rank and place, eight entries' atomics in flight
+      if (kMasked && 2u * g * 4u * kSortThreads >= n) break;  // (groups 2 g and 2 g + 1: beyond the region)
       uint32_t pos[8];
 #pragma unroll
       for (uint32_t k = 0; k < 8u; ++k) {
+        if (kMasked && k == 4u && (2u * g + 1u) * 4u * kSortThreads >= n) break;
         pos[k] = __hip_atomic_fetch_add((LdsWord) (uintptr_t) (e[8u * g + k] >> 16), 2u,
                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 8u; ++k) *((LdsHalf) (uintptr_t) pos[k]) = (uint16_t) e[8u * g + k];
+      for (uint32_t k = 0; k < 8u; ++k) {
+        // (slot of entry 8 g + k: group G = 2 g + k / 4, q = k % 4)
+        if (!kMasked || (2u * g + k / 4u) * 4u * kSortThreads + (k & 3u) + slot0 < n) {
+          *((LdsHalf) (uintptr_t) pos[k]) = (uint16_t) e[8u * g + k];
+        }
+      }
       asm volatile("" ::: "memory");
     }
     __syncthreads();
@@ -474,7 +496,15 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     {  // 4. the image leaves as one linear block
       const uint4 *s4 = reinterpret_cast<const uint4 *>(image);
       uint4 *d4 = reinterpret_cast<uint4 *>(b.sorted + start);
-      for (uint32_t i = threadIdx.x; i < kRegionEntries / 8u; i += kSortThreads) d4[i] = s4[i];
+      const uint32_t n8 = kMasked ? n >> 3 : kRegionEntries / 8u;
+      for (uint32_t i = threadIdx.x; i < n8; i += kSortThreads) d4[i] = s4[i];
+      if (kMasked && threadIdx.x < (n & 7u)) b.sorted[start + 8u * n8 + threadIdx.x] = image[8u * n8 + threadIdx.x];
+    }
+    };  // sort_region
+    if (n == kRegionEntries) {
+      sort_region(std::false_type());
+    } else {
+      sort_region(std::true_type());
     }
   } else {
   // 1. the region's entries, once: e[k] = (key << 16) | in-tile offset, ~0 beyond the region; counts per tile.
@@ -1144,10 +1174,13 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
     // the full regions first (lean instance: 10 vector instructions per entry), then the waves' last, partial ones
     se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes)
              : launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes);
-    if (se != hipSuccess) return se;
-    skip_lean = 1u;
-    se = few ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
-             : launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes);
+    // (a one-level plain stream: every region starts on a 16-byte boundary of its wave's segment -- cap is a multiple
+    // of 8 entries -- so the general instance has nothing left)
+    if (se == hipSuccess && (b.cap & 7u) != 0u) {
+      skip_lean = 1u;
+      se = few ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
+               : launch_sort(bin_region_sort_kernel<true, false>, SortLds<false>::kBytes);
+    }
 #endif
   } else if (few) {
     se = plain ? launch_sort(bin_region_sort_kernel<true, true>, SortLds<true>::kBytes)
