@@ -978,6 +978,63 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
   "s_add_u32 %[clk], %[clk], %[t]\n\t"                    \
   "18:\n\t"                                               \
   "s_sub_u32 %[ch], %[fill], %[ch]\n\t"
+// The loop on a CHUNKED stream (BinLayout::chunked: canvases beyond 1024 tiles; draw_wave.hip, CB_REPLAY_CHUNKED): the word
+// goes to the current chunk of its GROUP of 1024 tiles -- group = tile >> 10; the group's {next word, end of chunk} sit
+// in the wave's LDS at gcl + 8 * group; a returning add takes the place.  The step is ordered so that the LDS round
+// trip has the six fp64 instructions of z_{n+1} to hide behind (two waves per SIMD: nothing else would): record first
+// -- pixel, bounds, word, group, the two LDS instructions -- then z_{n+1}, then the store.  Lanes that find their
+// chunk full (`over`) keep word, group, place and limit in e / pidx / pos / lim; the burst ends behind that step and
+// replay_stage's caller opens new chunks for them (wide_open_chunks).  `fill` only counts the hits here.  23 vector
+// instructions per step.
+#define CBW_REPLAY_LOOP_CHUNKED                           \
+  "s_add_u32 %[cs], %[cs], %[t]\n\t"                      \
+  "v_cmp_nlt_f64_e64 %[alive], %[k16], %[a]\n\t"          \
+  "v_cmp_gt_u64_e64 %[hx], %[wb], %[fx]\n\t"              \
+  "v_cmp_gt_u64_e64 vcc, %[hb], %[fy]\n\t"                \
+  "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
+  "v_cvt_i32_f64 %[row], %[fy]\n\t"                       \
+  "v_mul_f64 %[a], %[i], %[i]\n\t"                        \
+  "v_mov_b32 %[lim], 1\n\t"                               \
+  "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
+  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  "s_mov_b64 %[hit], vcc\n\t"                             \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "v_lshrrev_b32 %[row], 7, %[row]\n\t"                   \
+  "v_lshrrev_b32 %[col], 7, %[col]\n\t"                   \
+  "v_mad_u32_u24 %[row], %[row], %[tlx], %[col]\n\t"      \
+  "v_lshrrev_b32 %[pidx], 10, %[row]\n\t"                 \
+  "v_lshl_add_u32 %[col], %[pidx], 3, %[gcl]\n\t"         \
+  "ds_add_rtn_u32 %[pos], %[col], %[lim]\n\t"             \
+  "ds_read_b32 %[lim], %[col] offset:4\n\t"               \
+  "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"                 \
+  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t" \
+  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
+  "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
+  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
+  "s_and_b64 %[act], %[act], %[alive]\n\t"                \
+  "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
+  "s_mov_b64 exec, %[hit]\n\t"                            \
+  "s_waitcnt lgkmcnt(0)\n\t"                              \
+  "v_cmp_lt_u32_e32 vcc, %[pos], %[lim]\n\t"              \
+  "s_andn2_b64 %[over], exec, vcc\n\t"                    \
+  "s_mov_b64 exec, vcc\n\t"                               \
+  "v_lshlrev_b32 %[pos], 2, %[pos]\n\t"                   \
+  "global_store_dword %[pos], %[e], %[base]\n\t"          \
+  "s_cmp_lg_u64 %[over], 0\n\t"                           \
+  "s_cbranch_scc1 8f\n\t"               /* (the step is complete: it counts) */ \
+  "s_mov_b64 exec, %[act]\n\t"                            \
+  "s_cbranch_execz 8f\n\t"                                \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                       \
+  "s_cbranch_scc0 1b\n\t"                                 \
+  "s_add_u32 %[clk], %[clk], %[n]\n\t"                    \
+  "s_branch 18f\n\t"                                      \
+  "8:\n\t"                                                \
+  "s_sub_u32 %[t], %[n], %[ctr]\n\t"                      \
+  "s_add_u32 %[clk], %[clk], %[t]\n\t"                    \
+  "18:\n\t"                                               \
+  "s_sub_u32 %[ch], %[fill], %[ch]\n\t"
 // `direct` != 0 (the wave's stream region is full; rare): the same loop with the hits added to the histogram by
 // device-scope atomics (a one-level canvas has at most 2^24 pixels: the byte offset of a pixel fits 32 bits).  BIN:
 // the text that forms fx, fy (a second copy of it).
@@ -1020,17 +1077,27 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
 // act: the lanes with an orbit in flight; q2_head / q2_count: the ring; min_active: fewest lanes a burst is run
 // for; n_steps: steps of a burst (>= 1); the stream region must have room for 64 * n_steps more entries unless
 // `direct`.  Returns the orbits popped; lane_steps / hits: the executed lane-steps and the points recorded.
-template <bool kPow2>
+// kChunked: the words that found their chunk full (lanes of `over`: word, group, the place they took, the chunk's end)
+struct ChunkOverflow {
+  unsigned long long over;
+  uint32_t word, group, pos, lim;
+};
+template <bool kPow2, bool kChunked>
 __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long long &act, uint32_t q2_head,
                                                  uint32_t q2_count, uint32_t q2_lds, uint32_t min_active,
                                                  uint32_t n_steps, uint32_t direct, Orbit &p, uint32_t &p_start,
                                                  uint32_t *region, uint32_t &fill, uint32_t &clock,
-                                                 uint32_t &lane_steps, uint32_t &hits) {
+                                                 uint32_t &lane_steps, uint32_t &hits, uint32_t cursors_lds,
+                                                 ChunkOverflow &ovf) {
   static_assert(kQ2Cap == 320, "ring length and plane distance in CBW_REPLAY_REFILL");
   unsigned long long save, alive, hx, scp;
   uint32_t cs, ch, ctr, t, nn;
   double a, fx, fy, d0, d1, d2, d3, ox, oy;
   uint32_t pidx, e, col, row;
+  unsigned long long over = 0ull, hit;
+  uint32_t pos = 0u, lim = 0u;
+  const uint32_t tlx = kChunked ? kernel_args()->bin.tiles_x : 0u;
+  cursors_lds = __builtin_amdgcn_readfirstlane(cursors_lds);
   const KernelArgs ka = kernel_args();
   const double wb = ka->replay_bound_w, hb = ka->replay_bound_h;  // (double) w, h: the bounds of the quotients, compared as bit patterns
   const uint32_t wi = (uint32_t) ka->w;
@@ -1059,13 +1126,32 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
       [wi] "s"(wi), [hist] "s"(hist), [base] "s"(region), [k16] "s"(k16)
   (void) ox;
   (void) oy;
-  if (kPow2) {
+#define CBW_CHUNKED_OUT [over] "+s"(over), [hit] "=&s"(hit), [pos] "+v"(pos), [lim] "+v"(lim)
+#define CBW_CHUNKED_IN [tlx] "s"(tlx), [gcl] "s"(cursors_lds)
+  if (kPow2 && kChunked) {
+    asm volatile("v_mov_b64 %[ox], %[oxs]\n\t"
+                 "v_mov_b64 %[oy], %[oys]\n\t"
+                 CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP_CHUNKED
+                 CBW_REPLAY_DIRECT(CBW_REPLAY_BIN_POW2) CBW_REPLAY_END
+                 : CBW_REPLAY_OUT, [ox] "=&v"(ox), [oy] "=&v"(oy), CBW_CHUNKED_OUT
+                 : CBW_REPLAY_IN, [oxs] "s"(oxs), [oys] "s"(oys), CBW_CHUNKED_IN
+                 : "vcc", "scc", "memory");
+  } else if (kPow2) {
     asm volatile("v_mov_b64 %[ox], %[oxs]\n\t"  // (in every lane: EXEC is all ones here, not behind the refill)
                  "v_mov_b64 %[oy], %[oys]\n\t"
                  CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_POW2 CBW_REPLAY_LOOP
                  CBW_REPLAY_DIRECT(CBW_REPLAY_BIN_POW2) CBW_REPLAY_END
                  : CBW_REPLAY_OUT, [ox] "=&v"(ox), [oy] "=&v"(oy)
                  : CBW_REPLAY_IN, [oxs] "s"(oxs), [oys] "s"(oys)
+                 : "vcc", "scc", "memory");
+  } else if (kChunked) {
+    const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
+    const double kg = 0.5 - 0x1p-24;
+    asm volatile(CBW_REPLAY_REFILL CBW_REPLAY_HEAD CBW_REPLAY_BIN_DIV CBW_REPLAY_LOOP_CHUNKED
+                 CBW_REPLAY_DIRECT(CBW_REPLAY_BIN_DIV2) CBW_REPLAY_END
+                 : CBW_REPLAY_OUT, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3),
+                   CBW_CHUNKED_OUT
+                 : CBW_REPLAY_IN, [ox] "s"(oxs), [oy] "s"(oys), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg), CBW_CHUNKED_IN
                  : "vcc", "scc", "memory");
   } else {
     const double rx = ka->rcp_delta_real, ry = ka->rcp_delta_imag;
@@ -1075,6 +1161,15 @@ __device__ __forceinline__ uint32_t replay_stage(uint32_t enable, unsigned long 
                  : CBW_REPLAY_OUT, [scp] "=&s"(scp), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)
                  : CBW_REPLAY_IN, [ox] "s"(oxs), [oy] "s"(oys), [rx] "s"(rx), [ry] "s"(ry), [kg] "s"(kg)
                  : "vcc", "scc", "memory");
+  }
+#undef CBW_CHUNKED_OUT
+#undef CBW_CHUNKED_IN
+  if (kChunked) {
+    ovf.over = uniform_u64(over);
+    ovf.word = e;
+    ovf.group = pidx;
+    ovf.pos = pos;
+    ovf.lim = lim;
   }
 #undef CBW_REPLAY_OUT
 #undef CBW_REPLAY_IN
@@ -1134,6 +1229,31 @@ __device__ __forceinline__ unsigned long long long_tail(unsigned long long mask,
   return escaped;
 }
 
+// kChunked, behind a burst that ended with words left over (draw_wave.hip, replay_burst_chunked): group by group, open
+// the next free chunk of the wave's segment, put the words at its start -- the places they took run on from the old
+// chunk's end, lim -- and the group's cursor behind them.  Once per kChunkWords words of a group.
+__device__ __forceinline__ void wide_open_chunks(const ChunkOverflow &v, uint32_t *region, uint32_t *cursors,
+                                                 uint32_t &next_chunk, uint32_t *desc) {
+  unsigned long long over = v.over;
+  asm volatile("" : "+s"(region), "+s"(desc));
+  while (over != 0ull) {
+    const int lane0 = __ffsll((long long) over) - 1;
+    const uint32_t g0 = (uint32_t) __builtin_amdgcn_readlane((int) v.group, lane0);
+    const uint32_t lim0 = (uint32_t) __builtin_amdgcn_readlane((int) v.lim, lane0);
+    const bool mine = lane_in(over) && v.group == g0;
+    const unsigned long long same = uniform_u64(__ballot(mine));
+    const uint32_t first = next_chunk * kChunkWords;
+    if (mine) region[first + (v.pos - lim0)] = v.word;
+    if (lane_id() == lane0) {
+      desc[next_chunk] = (g0 << 16) | kChunkWords;  // taken as full; the launch's end corrects the last one of each group
+      cursors[2u * g0] = first + (uint32_t) __popcll(same);
+      cursors[2u * g0 + 1u] = first + kChunkWords;
+    }
+    next_chunk++;
+    over &= ~same;
+  }
+}
+
 __device__ __forceinline__ int q1_wrap(int slot) { return slot >= kQ1Cap ? slot - kQ1Cap : slot; }
 __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot - kQ2Cap : slot; }
 
@@ -1141,11 +1261,23 @@ __device__ __forceinline__ int q2_wrap(int slot) { return slot >= kQ2Cap ? slot 
 // the IEEE division behind it (CBW_REPLAY_BIN_DIV) -- an instance of its own, so that the division's temporaries do
 // not count against the other's registers.
 // kTimed: stage clocks (s_memtime) into cb_counters, like draw_wave_kernel's timed variant (--kernel timed).
-template <bool kPow2, bool kTimed>
+// kChunked: the stream chunked by group of 1024 tiles as it is written (canvases beyond 1024 tiles).
+template <bool kPow2, bool kTimed, bool kChunked>
 __global__ void __launch_bounds__(64 * kWavesPerBlock, 4)  // at most 128 vector registers: two of these waves and the
 draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 each) share a SIMD's 512
   __shared__ WideQueues queues[kWavesPerBlock];
   WideQueues &q = queues[threadIdx.x >> 6];
+  // kChunked: the groups' cursors, 512 bytes per wave of DYNAMIC LDS (launch_draw_wide): as static LDS they would
+  // take the workgroup beyond a quarter of the CU's 160 KiB, and the compiler, seeing room for three waves per SIMD
+  // only, would help itself to more than 128 registers
+  extern __shared__ uint32_t group_cursors[];
+  uint32_t *const my_cursors = group_cursors + (kChunked ? (threadIdx.x >> 6) * 2u * kChunkedGroupsMax : 0u);
+  if (kChunked) {
+    for (uint32_t k = threadIdx.x & 63u; k < 2u * kChunkedGroupsMax; k += 64u) my_cursors[k] = 0u;  // no chunk yet
+  }
+  const uint32_t cursors_lds = kChunked ? __builtin_amdgcn_readfirstlane(
+      (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(my_cursors))) : 0u;
+  uint32_t next_chunk = 0;  // kChunked: the first chunk of the wave's (double) segment that is still free
 
   // this wave: subsequences [128 wave_id, 128 wave_id + 128): generator A of lane l is subsequence 128 wave_id + l,
   // generator B 128 wave_id + 64 + l; stream segments 2 wave_id and 2 wave_id + 1 of the workspace (contiguous)
@@ -1319,14 +1451,24 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     if (do_replay) {
       // The visited pixels go to this wave's stream region (compacted, coalesced stores); a full region makes the
       // burst add to the histogram directly, so the result never depends on the workspace size.
-      const uint32_t direct = (region_fill + 64u * kReplayBurst <= region_cap) ? 0u : 1u;
+      // (kChunked: a burst opens at most one chunk per group and one per kChunkWords words)
+      const KernelArgs ra = kernel_args();
+      const uint32_t direct =
+          kChunked ? ((next_chunk + ra->bin.n_groups + 64u * kReplayBurst / kChunkWords + 1u <= 2u * ra->bin.chunks_per_wave) ? 0u : 1u)
+                   : ((region_fill + 64u * kReplayBurst <= region_cap) ? 0u : 1u);
+      ChunkOverflow ovf;
       uint32_t steps = 0, hits = 0, popped;
 #ifdef CB_WIDE_PROBE
       const uint32_t clock_before = replay_clock;
 #endif
-      popped = replay_stage<kPow2>(do_replay ? 1u : 0u, pact, (uint32_t) q2_head, (uint32_t) q2_count, q2_lds,
-                                   draining ? 1u : (uint32_t) kReplayMin, kReplayBurst, direct, po, p_start, region,
-                                   region_fill, replay_clock, steps, hits);
+      popped = replay_stage<kPow2, kChunked>(do_replay ? 1u : 0u, pact, (uint32_t) q2_head, (uint32_t) q2_count, q2_lds,
+                                             draining ? 1u : (uint32_t) kReplayMin, kReplayBurst, direct, po, p_start,
+                                             region, region_fill, replay_clock, steps, hits, cursors_lds, ovf);
+      if (kChunked && ovf.over != 0ull) {
+        wide_open_chunks(ovf, region, my_cursors, next_chunk,
+                         ra->bin.chunk_desc + (size_t) (2u * wave_id) * ra->bin.chunks_per_wave);
+        next_chunk = __builtin_amdgcn_readfirstlane(next_chunk);
+      }
       q2_head = q2_wrap(q2_head + (int) popped);
       q2_count -= (int) popped;
       n_recorded += popped;
@@ -1502,7 +1644,23 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     store_rng(st, nt, ta, rng.a);
     store_rng(st, nt, ta + 64u, rng.b);
   }
-  if (lane_id() == 0) {  // the wave's segment as the two segments the scatter knows
+  if (kChunked) {
+    // the last chunk of every group holds what its cursor says; every other chunk in use is full.  The wave's chunks
+    // as those of the two segments the scatter knows (their rows of chunk_desc lie side by side).
+    const uint32_t cpw = ea->bin.chunks_per_wave;
+    uint32_t *desc = ea->bin.chunk_desc + (size_t) (2u * wave_id) * cpw;
+    asm volatile("" : "+s"(desc));
+    const uint32_t g = (uint32_t) lane_id();
+    if (g < ea->bin.n_groups) {
+      const uint32_t pos = my_cursors[2u * g], lim = my_cursors[2u * g + 1u];
+      if (lim != 0u) desc[lim / kChunkWords - 1u] = (g << 16) | (pos - (lim - kChunkWords));
+    }
+    if (lane_id() == 0) {
+      uint32_t *const wc = ea->bin.wave_count;
+      wc[2u * wave_id] = next_chunk < cpw ? next_chunk : cpw;
+      wc[2u * wave_id + 1u] = next_chunk < cpw ? 0u : next_chunk - cpw;
+    }
+  } else if (lane_id() == 0) {  // the wave's segment as the two segments the scatter knows
     uint32_t *const wc = ea->bin.wave_count;
     const uint32_t cap = ea->bin.cap;
     wc[2u * wave_id] = region_fill < cap ? region_fill : cap;
@@ -1585,7 +1743,12 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
 #ifndef CB_BURNING_SHIP
 // Can this kernel take the launch?  (Everything else is draw_wave_kernel's.)
 bool draw_wide_takes(const DrawArgs &a) {
-  const bool binned_one_level = a.bin.enabled != 0u && a.bin.two_level == 0u && a.bin.chunked == 0u;
+  // a one-level stream, or a chunked one on a canvas whose pixels' byte offsets fit 32 bits (the direct form of the burst)
+  const bool binned_one_level =
+      a.bin.enabled != 0u &&
+      ((a.bin.two_level == 0u && a.bin.chunked == 0u) ||
+       (a.bin.chunked != 0u && a.bin.n_planes == 1u && a.bin.e_row_shift == 16u &&
+        (unsigned long long) a.w * (unsigned long long) a.h < (1ull << 29)));
   const bool usual_split = a.head_steps == kHeadSteps && a.fast_mid != 0 && a.sparse_long != 0 &&
                            a.min_iter == a.long_start && a.max_iter > a.long_start;
   return binned_one_level && usual_split && a.n_channels == 0 && a.carry != nullptr && a.n_threads != 0u &&
@@ -1600,17 +1763,22 @@ hipError_t CB_LAUNCH_NAME(const DrawArgs &a, bool timed, hipStream_t stream) {
   const uint32_t threads = 64 * kWavesPerBlock;
   const uint32_t blocks = a.n_threads / (128u * kWavesPerBlock);
   const bool pow2 = a.pow2_real && a.pow2_imag;
-  if (timed) {
-    if (pow2) {
-      hipLaunchKernelGGL((draw_wide_kernel<true, true>), dim3(blocks), dim3(threads), 0, stream, a);
+  const bool chunked = a.bin.chunked != 0u;
+#define CBW_LAUNCH(P, T, C)                                                                                        \
+  hipLaunchKernelGGL((draw_wide_kernel<P, T, C>), dim3(blocks), dim3(threads),                                     \
+                     (C) ? kWavesPerBlock * 2u * kChunkedGroupsMax * sizeof(uint32_t) : 0u, stream, a)
+  if (chunked) {
+    if (timed) {
+      if (pow2) CBW_LAUNCH(true, true, true); else CBW_LAUNCH(false, true, true);
     } else {
-      hipLaunchKernelGGL((draw_wide_kernel<false, true>), dim3(blocks), dim3(threads), 0, stream, a);
+      if (pow2) CBW_LAUNCH(true, false, true); else CBW_LAUNCH(false, false, true);
     }
-  } else if (pow2) {
-    hipLaunchKernelGGL((draw_wide_kernel<true, false>), dim3(blocks), dim3(threads), 0, stream, a);
+  } else if (timed) {
+    if (pow2) CBW_LAUNCH(true, true, false); else CBW_LAUNCH(false, true, false);
   } else {
-    hipLaunchKernelGGL((draw_wide_kernel<false, false>), dim3(blocks), dim3(threads), 0, stream, a);
+    if (pow2) CBW_LAUNCH(true, false, false); else CBW_LAUNCH(false, false, false);
   }
+#undef CBW_LAUNCH
   return hipGetLastError();
 }
 

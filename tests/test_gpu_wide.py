@@ -1,7 +1,8 @@
 """draw_wide_kernel (draw_wide.hip): the two-waves-per-SIMD draw kernel that runs beside the scatter.
 
-It takes the launches of the usual configuration (a one-level scatter workspace, one channel, min_iter at the start of
-the LONG stage, a carry buffer, whole workgroups of 512 subsequences); everything else is draw_wave_kernel's.  Same
+It takes the launches of the usual configuration (a one-level scatter workspace or a chunked one, one channel, min_iter
+at the start of the LONG stage, a carry buffer, whole workgroups of 512 subsequences); everything else is
+draw_wave_kernel's.  Same
 bar as everywhere: bit-exact histograms and exact counters against the oracle -- and against draw_wave_kernel for the
 same launches (CUDABROT_AMD_NO_WIDE=1, a test knob), with cb_debug_last_draw_kernel telling which kernel ran.
 """
@@ -116,6 +117,71 @@ def test_wide_kernel_with_a_stream_region_too_small_adds_directly(cb, oracle):
         assert cnt[k] == rc[k], k
     # the stream held only part of the increments: the rest went the direct way
     assert cnt["increments"] > 2 * threads * 200
+
+
+CHUNKED = [
+    dict(w=1300, h=900, max_iter=600, min_iter=20, threads=8192, passes=3),                    # 88 tiles, division
+    dict(w=1024, h=2048, max_iter=600, min_iter=20, threads=4096, passes=4),                   # dyadic pixels
+    dict(w=9100, h=8300, max_iter=400, min_iter=20, threads=16384, passes=2, box=(-2.0, 1.5, -1.6, 1.6)),  # five groups
+]
+
+
+@pytest.mark.parametrize("cfg", CHUNKED, ids=["forced_88_tiles", "forced_dyadic", "five_groups"])
+def test_wide_kernel_on_a_chunked_stream(cb, oracle, monkeypatch, cfg):
+    """Canvases beyond 1024 tiles (and smaller ones made to behave so: CUDABROT_AMD_TWO_LEVEL=1): the stream is
+    chunked by group of tiles as the draw kernel writes it; draw_wide_kernel's chunked burst against the oracle and
+    against draw_wave_kernel's."""
+    monkeypatch.setenv("CUDABROT_AMD_TWO_LEVEL", "1")
+    box = cfg.get("box", BOX)
+    args = (cfg["w"], cfg["h"], cfg["max_iter"], cfg["min_iter"], cfg["threads"], cfg["passes"], box)
+    wide = render(cb, *args)
+    assert wide[2] == WIDE, "the launch was not taken by draw_wide_kernel"
+    timed = render(cb, *args, variant=cb.CB_KERNEL_TIMED)
+    assert timed[2] == WIDE
+    same(wide, timed)
+    monkeypatch.setenv("CUDABROT_AMD_NO_WIDE", "1")
+    wave = render(cb, *args)
+    assert wave[2] == WAVE
+    same(wide, wave)
+    ref = oracle.render(*args[:6], box, omp_threads=0)
+    assert np.array_equal(wide[0], ref[0])
+    for k in ("samples", "rejected", "never_escaped", "too_fast", "recorded", "iterate_steps", "replay_steps", "increments"):
+        assert wide[1][k] == ref[1][k], (k, wide[1][k], ref[1][k])
+
+
+@pytest.mark.parametrize("passes", [3, 6])
+def test_wide_kernel_that_runs_out_of_chunks_adds_directly(cb, oracle, passes):
+    """Five groups and a workspace sized for a launch of 50 samples per subsequence, filled by ONE launch of 150 / 300:
+    a wave without enough free chunks for a burst adds its increments to the histogram directly (byte offsets of 32
+    bits: what draw_wide_takes asks of the canvas)."""
+    import torch
+
+    fraction = 1.0
+    w, h, max_iter, threads = 9100, 8300, 400, 16384
+    box = (-2.0, 1.5, -1.6, 1.6)
+    dims = cb.FractalDimensions.make(w, h, *box)
+    it = cb.IterationControl(max_iter, 20)
+    dev = torch.device("cuda", 0)
+    size = int(cb.scatter_workspace_bytes(dims, threads, 50) * fraction)
+    hist = torch.zeros(w * h, dtype=torch.int64, device=dev)
+    states = torch.empty(cb.rng_state_bytes(threads), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    ws = torch.empty(size, dtype=torch.uint8, device=dev)
+    carry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, 0, threads, states.data_ptr(), stream)
+    for n in (50 * passes, 0):
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, n, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, ws.data_ptr(), size, carry.data_ptr())
+        assert cb.lib.cb_debug_last_draw_kernel() == WIDE
+        cb.flush_scatter(dims, hist.data_ptr(), threads, ws.data_ptr(), size, stream)
+    torch.cuda.synchronize()
+    cnt = dict(zip(cb.Counters().as_dict().keys(), (int(v) for v in counters.cpu().numpy().view(np.uint64))))
+    got = hist.cpu().numpy().view(np.uint64).reshape(h, w)
+    ref, rc = oracle.render(w, h, max_iter, 20, threads, passes, box, omp_threads=0)
+    assert cnt["status"] == 0 and np.array_equal(got, ref)
+    for k in ("samples", "recorded", "iterate_steps", "replay_steps", "increments"):
+        assert cnt[k] == rc[k], k
 
 
 def test_launches_the_wide_kernel_does_not_take(cb, monkeypatch):
