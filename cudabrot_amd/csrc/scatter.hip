@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   // image, so that the ranking pass is ONE vector instruction per entry (the address out of the packed word).  10
   // vector instructions per entry all told instead of 36: alone on the GPU the sort is memory-bound either way, beside
   // the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
-  const bool lean_region = kPlain && !kChunked && n != 0u && (start & 7ull) == 0ull;
+  const bool lean_region = kPlain && n != 0u && (kChunked || (start & 7ull) == 0ull);
   if (!kLean && skip_lean != 0u && lean_region) continue;  // (the lean instance's)
   if (kLean && !lean_region) continue;
   if constexpr (kLean) {
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     const uint32_t image_at = (uint32_t) reinterpret_cast<uintptr_t>(static_cast<void *>(image));
     const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
     const uint32_t tiles_x = b.tiles_x;
-    constexpr uint32_t kBatch = CB_LEAN_BATCH;  // 16-byte loads in flight per thread
+    constexpr uint32_t kBatch = kChunked ? 2u : CB_LEAN_BATCH;  // 16-byte loads in flight per thread (chunked: 64-bit addresses)
     // kMasked: a region that is not full (a wave's last): loads clamped to the region, the slots beyond it count into the
     // replica's dummy counter and are not placed -- two or three more instructions per entry, on a tenth of them
     const auto sort_region = [&](auto masked) {
@@ -418,33 +418,51 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     const uint32_t dummy_at = lds0 + (uint32_t) (((threadIdx.x % kCntReplicas) * kCntStride + kDummyKey) * sizeof(uint32_t));
     const uint32_t last4 = (n - 1u) >> 2;
     const uint32_t slot0 = 4u * threadIdx.x;  // this thread's slots: 4096 G + slot0 + q, G = 0..7
+    // kChunked: slot group G is the region's chunks 4 G .. 4 G + 3, this thread's 16 bytes the in_chunk-th of chunk
+    // 4 G + my_chunk (the same chunk for the whole wave); a slot holds an entry if it lies below the chunk's words
+    const uint32_t my_chunk = threadIdx.x >> 8, in_chunk = threadIdx.x & 255u;
+    const uint32_t n_chunks = kChunked ? __builtin_amdgcn_readfirstlane(b.region_count[r]) : 0u;
+    const auto beyond = [&](uint32_t G) {  // (wave-uniform) nothing of slot group G lies inside the region
+      return kChunked ? 4u * G >= n_chunks : (kMasked && G * 4u * kSortThreads >= n);
+    };
     uint32_t e[kSortPerThread];
     // 1. the entries, once: e = counter address << 16 | in-tile offset (7 vector instructions per entry); the counters
     //    count BYTES of the image (2 per entry), so that the ranking below gets an entry's place as an address
 #pragma unroll
     for (uint32_t part = 0; part < kSortPerThread / 4u / kBatch; ++part) {
       uint4 v[kBatch];
+      uint32_t words_g[kBatch];
 #pragma unroll
       for (uint32_t j = 0; j < kBatch; ++j) {
         const uint32_t i4 = (part * kBatch + j) * kSortThreads + threadIdx.x;
-        v[j] = src4[kMasked ? (i4 < last4 ? i4 : last4) : i4];
+        if (kChunked) {  // (a chunk the region does not have: {0, 0} -- the start of the stream, no words)
+          const uint2 cd = chunks[4u * (part * kBatch + j) + my_chunk];
+          words_g[j] = cd.y;
+          v[j] = src4[(size_t) (cd.x >> 2) + in_chunk];
+        } else {
+          v[j] = src4[kMasked ? (i4 < last4 ? i4 : last4) : i4];
+        }
       }
 #pragma unroll
       for (uint32_t j = 0; j < kBatch; ++j) {
         // (the slots 4096 G .. 4096 G + 4095 of group G = part * kBatch + j: none inside the region -- nothing to count)
-        if (kMasked && (part * kBatch + j) * 4u * kSortThreads >= n) break;
+        if (beyond(part * kBatch + j)) break;
         asm volatile("" : "+v"(v[j].x), "+v"(v[j].y), "+v"(v[j].z), "+v"(v[j].w));
         const uint32_t words[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
         for (uint32_t q = 0; q < 4; ++q) {
-          const uint32_t w = words[q];  // row << 16 | col, col < 16384 (the host's condition for this instance)
+          const uint32_t w = words[q];  // row << 16 | col; not chunked: col < 16384 (the host's condition for the instance)
           const uint32_t key = __umul24(w >> (16 + kTileShift), tiles_x) + __builtin_amdgcn_ubfe(w, kTileShift, 16 - kTileShift);
           uint32_t addr = cnt_at + (key << 2);  // < 2^16: at most 8 replicas of 272 or 2 of 1040 counters
-          if (kMasked && !((part * kBatch + j) * 4u * kSortThreads + q + slot0 < n)) addr = dummy_at;
+          if (kChunked ? !(4u * in_chunk + q < words_g[j])
+                       : (kMasked && !((part * kBatch + j) * 4u * kSortThreads + q + slot0 < n))) {
+            addr = dummy_at;
+          }
           __hip_atomic_fetch_add((LdsWord) (uintptr_t) addr, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           // bits 7..13 from the row, the rest as it is: bits 0..6 are the column's, 14 and 15 are 0, and what lies
           // above is cut off by the byte select that joins address and offset
-          const uint32_t off = ((w >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) | (w & ~((kTileSize - 1u) << kTileShift));
+          const uint32_t off = ((w >> (16 - kTileShift)) & ((kTileSize - 1u) << kTileShift)) |
+                               (w & (kChunked ? kTileSize - 1u : ~((kTileSize - 1u) << kTileShift)));
           uint32_t packed = __builtin_amdgcn_perm(addr, off, 0x05040100u);  // addr << 16 | off & 0xffff
           asm volatile("" : "+v"(packed));  // formed HERE (else address and offset are kept apart until the ranking pass)
           e[4u * (part * kBatch + j) + q] = packed;
@@ -474,20 +492,22 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
     __builtin_amdgcn_s_setprio(CB_SORT_PRIO_RANK);
 #pragma unroll
     for (uint32_t g = 0; g < kSortPerThread / 8u; ++g) {  // 3. rank and place, eight entries' atomics in flight
-      if (kMasked && 2u * g * 4u * kSortThreads >= n) break;  // (groups 2 g and 2 g + 1: beyond the region)
+      if (beyond(2u * g)) break;  // (groups 2 g and 2 g + 1: beyond the region)
       uint32_t pos[8];
+      const uint32_t words_a = kChunked ? chunks[4u * (2u * g) + my_chunk].y : 0u;
+      const uint32_t words_b = kChunked ? chunks[4u * (2u * g + 1u) + my_chunk].y : 0u;
 #pragma unroll
       for (uint32_t k = 0; k < 8u; ++k) {
-        if (kMasked && k == 4u && (2u * g + 1u) * 4u * kSortThreads >= n) break;
+        if (k == 4u && beyond(2u * g + 1u)) break;
         pos[k] = __hip_atomic_fetch_add((LdsWord) (uintptr_t) (e[8u * g + k] >> 16), 2u,
                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_add_rtn_u32
       }
 #pragma unroll
       for (uint32_t k = 0; k < 8u; ++k) {
         // (slot of entry 8 g + k: group G = 2 g + k / 4, q = k % 4)
-        if (!kMasked || (2u * g + k / 4u) * 4u * kSortThreads + (k & 3u) + slot0 < n) {
-          *((LdsHalf) (uintptr_t) pos[k]) = (uint16_t) e[8u * g + k];
-        }
+        const bool inside = kChunked ? 4u * in_chunk + (k & 3u) < (k < 4u ? words_a : words_b)
+                                     : (!kMasked || (2u * g + k / 4u) * 4u * kSortThreads + (k & 3u) + slot0 < n);
+        if (inside) *((LdsHalf) (uintptr_t) pos[k]) = (uint16_t) e[8u * g + k];
       }
       asm volatile("" ::: "memory");
     }
@@ -499,9 +519,10 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
       const uint32_t n8 = kMasked ? n >> 3 : kRegionEntries / 8u;
       for (uint32_t i = threadIdx.x; i < n8; i += kSortThreads) d4[i] = s4[i];
       if (kMasked && threadIdx.x < (n & 7u)) b.sorted[start + 8u * n8 + threadIdx.x] = image[8u * n8 + threadIdx.x];
+      if (kChunked && threadIdx.x == 0) b.region_count[r] = n;  // from chunks to entries (every region is sorted once)
     }
     };  // sort_region
-    if (n == kRegionEntries) {
+    if (!kChunked && n == kRegionEntries) {
       sort_region(std::false_type());
     } else {
       sort_region(std::true_type());
@@ -1167,7 +1188,11 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   };
   hipError_t se;
   if (b.chunked) {
+#ifndef CB_NO_LEAN_SORT
+    se = plain ? launch_sort(bin_region_sort_kernel<true, false, true, true>, SortLds<false>::kBytes)
+#else
     se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
+#endif
                : launch_sort(bin_region_sort_kernel<false, false, true>, SortLds<false>::kBytes);
 #ifndef CB_NO_LEAN_SORT
   } else if (plain && !b.two_level && b.tiles_x <= 128u) {  // (columns below 16384: the lean instance's word)
