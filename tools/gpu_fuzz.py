@@ -65,7 +65,7 @@ def trial(rng):
         t["windows"] = [(rng.choice([30, 100, 400, 2500]), rng.choice([0, 5, 20, 50, 300])) for _ in range(rng.randint(1, 4))]
     if rng.random() < 0.35:
         # a launch draw_wide_kernel takes (draw_wide.hip): whole workgroups of 512 subsequences, min_iter at the start
-        # of the LONG stage, one level, one channel, a carry buffer, a workspace (suggested or short: a full stream
+        # of the LONG stage, one level or a chunked stream, one channel, a carry buffer, a workspace (suggested or short: a full stream
         # region makes the bursts add directly); tails of every length through max_iter
         t["threads"] = rng.choice([512, 1024, 2048, 4096, 16384])
         t["min_iter"] = 20
@@ -73,7 +73,7 @@ def trial(rng):
         t["launch_samples"] = [rng.choice([30, 50, 64, 100, 150, 400]) for _ in range(rng.randint(1, 4))]
         t["workspace"] = rng.choice(["suggested", "suggested", "short"])
         t["carry"] = rng.choice(["drain_launch", "drain_flag"])
-        t["two_level"] = False
+        t["two_level"] = rng.random() < 0.3      # (chunked stream: the wide kernel's chunked burst; a counting sort: draw_wave_kernel's)
         t["windows"] = None
     if t["max_iter"] >= 5000:   # keep the lock-step kernel's run time in hand
         t["threads"] = min(t["threads"], 4096)
