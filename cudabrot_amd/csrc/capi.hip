@@ -9,6 +9,7 @@
 
 #include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -44,6 +45,67 @@ int device_matrices(const uint32_t **out) {
   }
   *out = g_matrices[dev];
   return 0;
+}
+
+// The interior map (DrawArgs::interior_map; tools/interior_map.c makes and proves it, `make` builds it beside the
+// library as interior_map.bin): one copy per device, read on first use from CUDABROT_AMD_INTERIOR_MAP or from the
+// directory of this library / binary (or its cudabrot_amd/ subdirectory).  No file: no map -- the same results, the
+// never-escaping samples at their old price.
+struct InteriorMap {
+  const unsigned char *d_bits;
+  uint32_t level, cols, rows;
+};
+std::mutex g_interior_mutex;
+InteriorMap g_interior[64];
+bool g_interior_tried[64] = {false};
+int g_interior_level = 0;  // cb_debug_interior_map_level: the level of the map the last launch used (0: none)
+
+FILE *open_interior_map() {
+  if (const char *e = getenv("CUDABROT_AMD_INTERIOR_MAP")) return fopen(e, "rb");
+  Dl_info info;
+  if (!dladdr(reinterpret_cast<const void *>(&open_interior_map), &info) || !info.dli_fname) return nullptr;
+  std::string dir(info.dli_fname);
+  const size_t slash = dir.rfind('/');
+  dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+  for (const char *rel : {"/interior_map.bin", "/cudabrot_amd/interior_map.bin"}) {
+    if (FILE *f = fopen((dir + rel).c_str(), "rb")) return f;
+  }
+  return nullptr;
+}
+
+const InteriorMap *device_interior_map() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_interior_mutex);
+  if (!g_interior_tried[dev]) {
+    g_interior_tried[dev] = true;
+    g_interior[dev] = InteriorMap{nullptr, 0u, 0u, 0u};
+    if (FILE *f = open_interior_map()) {
+      uint32_t header[4] = {0, 0, 0, 0};
+      std::vector<unsigned char> bits;
+      bool ok = fread(header, 1, 16, f) == 16 && header[0] == 0x4d494243u && header[1] >= 8u && header[1] <= 15u &&
+                header[2] == (5u << header[1]) / 2u && header[3] == (5u << header[1]) / 4u;  // 2.5 and 1.25 * 2^level
+      if (ok) {
+        const size_t bytes = ((size_t) header[2] * header[3] + 7) / 8;
+        bits.resize(bytes);
+        ok = fread(bits.data(), 1, bytes, f) == bytes;
+      }
+      fclose(f);
+      if (ok) {
+        unsigned char *d = nullptr;
+        if (hipMalloc(&d, bits.size()) == hipSuccess) {
+          if (hipMemcpy(d, bits.data(), bits.size(), hipMemcpyHostToDevice) == hipSuccess) {
+            g_interior[dev] = InteriorMap{d, header[1], header[2], header[3]};
+          } else {
+            (void) hipFree(d);
+          }
+        }
+      } else {
+        fprintf(stderr, "cudabrot_amd: the interior map file is not one (ignored)\n");
+      }
+    }
+  }
+  return g_interior[dev].d_bits ? &g_interior[dev] : nullptr;
 }
 
 // x / delta == x * (1 / delta) bit for bit iff delta is a (normal) power of two.
@@ -330,6 +392,7 @@ extern "C" {
 int cb_abi_version(void) { return CB_ABI_VERSION; }
 
 int cb_debug_last_draw_kernel(void) { return g_last_draw_kernel; }
+int cb_debug_interior_map_level(void) { return g_interior_level; }
 
 const char *cb_error_string(int code) {
   if (code == 0) return "no error";
@@ -397,6 +460,19 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   const bool wide = cb::draw_wide_takes(a) && cb_debug_knob("CUDABROT_AMD_NO_WIDE") == nullptr;
   const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
   g_last_draw_kernel = base_variant == CB_KERNEL_SIMPLE ? 3 : (wide ? 2 : 1);
+  g_interior_level = 0;
+  // the interior map: the wide kernel's, where orbits may be retired early at all (CUDABROT_AMD_NO_INTERIOR_MAP=1, a
+  // test knob: never)
+  if (wide && !ship && base_variant != CB_KERNEL_FULL_ITERATE && cb_debug_knob("CUDABROT_AMD_TIMED_FULL") == nullptr &&
+      cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") == nullptr) {
+    if (const InteriorMap *m = device_interior_map()) {
+      a.interior_map = m->d_bits;
+      a.interior_shift = m->level - 1u;
+      a.interior_cols = m->cols;
+      a.interior_rows = m->rows;
+      g_interior_level = (int) m->level;
+    }
+  }
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
       return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));

@@ -467,14 +467,24 @@ __device__ __forceinline__ Xorwow xorwow_rotated4(const Xorwow &s) {
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
   "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+// map / shift / cols / rows: the interior map (DrawArgs::interior_map; map = 0: none).  The cell of every popped c is
+// looked up while the stage iterates -- column floor((Cr + 4) 2^shift), row floor(|Ci| 2^shift) on doubled coordinates,
+// one byte load per lane behind the LDS reads, waited for in front of the push -- and a lane whose cell is marked is not
+// pushed: `hit` (among the lanes of `take`; the caller counts those of `alive` as never-escaping and takes one outside
+// `alive`, a sample of a proven cell that escaped, for the broken invariant it would be).
 __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_plus_head,
                                          uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
                                          uint32_t q1_lds, unsigned long long &alive,
-                                         uint32_t &lane_steps) {
+                                         uint32_t &lane_steps, unsigned long long map, uint32_t shift,
+                                         uint32_t cols, uint32_t rows, unsigned long long &hit) {
   static_assert(kQ0Cap == 128 && kQ1Cap == 96 && kHeadSteps == 4, "ring mask, ring length and plane distances below");
-  unsigned long long save;
-  uint32_t cnt, tmp, ctr, slot, wr;
+  unsigned long long save, t64;
+  uint32_t cnt, tmp, ctr, slot, wr, mbit, hitb;
   double cr, ci, r, i, a;
+  map = uniform_u64(map);
+  shift = __builtin_amdgcn_readfirstlane(shift);
+  cols = __builtin_amdgcn_readfirstlane(cols);
+  rows = __builtin_amdgcn_readfirstlane(rows);
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b64 exec, %[take]\n\t"
@@ -484,7 +494,28 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "ds_read_b64 %[ci], %[slot] offset:1024\n\t"
       "s_mov_b32 %[cnt], 0\n\t"
       "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_mov_b64 %[hit], 0\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
+      "s_cmp_eq_u64 %[map], 0\n\t"
+      "s_cbranch_scc1 10f\n\t"
+      "v_add_f64 %[a], %[cr], 4.0\n\t"
+      "v_ldexp_f64 %[a], %[a], %[shift]\n\t"
+      "v_cmp_le_f64_e32 vcc, 0, %[a]\n\t"
+      "v_cvt_u32_f64 %[slot], %[a]\n\t"
+      "v_ldexp_f64 %[a], |%[ci]|, %[shift]\n\t"
+      "v_cvt_u32_f64 %[wr], %[a]\n\t"
+      "v_cmp_gt_u32_e64 %[t64], %[cols], %[slot]\n\t"
+      "s_and_b64 vcc, vcc, %[t64]\n\t"
+      "v_cmp_gt_u32_e64 %[t64], %[rows], %[wr]\n\t"
+      "s_and_b64 vcc, vcc, %[t64]\n\t"
+      "v_mad_u32_u24 %[slot], %[wr], %[cols], %[slot]\n\t"
+      "v_and_b32 %[mbit], 7, %[slot]\n\t"
+      "v_lshrrev_b32 %[slot], 3, %[slot]\n\t"
+      "v_mov_b32 %[hitb], 0\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "global_load_ubyte %[hitb], %[slot], %[map]\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "10:\n\t"
       // HEAD's iterations again, from z = c (first product: I*I with I = ci)
       "v_mul_f64 %[a], %[ci], %[ci]\n\t"
       "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
@@ -511,6 +542,16 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_cbranch_scc1 1b\n\t"
       "2:\n\t"
       "s_mov_b64 %[alive], exec\n\t"
+      "s_cmp_eq_u64 %[map], 0\n\t"
+      "s_cbranch_scc1 11f\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "v_lshrrev_b32 %[hitb], %[mbit], %[hitb]\n\t"
+      "v_and_b32 %[hitb], 1, %[hitb]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[hitb]\n\t"
+      "s_mov_b64 %[hit], vcc\n\t"
+      "s_andn2_b64 exec, %[alive], vcc\n\t"
+      "11:\n\t"
       "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
       "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
       "v_add_u32 %[slot], %[tail], %[slot]\n\t"          // < 96 + 64
@@ -525,9 +566,9 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_nop 4\n\t"
       : [alive] "=&s"(alive), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr),
         [slot] "=&v"(slot), [wr] "=&v"(wr), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r),
-        [i] "=&v"(i)
+        [i] "=&v"(i), [hit] "=&s"(hit), [t64] "=&s"(t64), [mbit] "=&v"(mbit), [hitb] "=&v"(hitb)
       : [take] "s"(take), [lph] "v"(lane_plus_head), [q0] "s"(q0_lds), [n] "s"(n_steps),
-        [tail] "v"(q1_tail), [q1] "s"(q1_lds)
+        [tail] "v"(q1_tail), [q1] "s"(q1_lds), [map] "s"(map), [shift] "s"(shift), [cols] "s"(cols), [rows] "s"(rows)
       : "vcc", "scc", "memory");
   lane_steps = cnt;
 }
@@ -1332,6 +1373,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   uint32_t p_start = 0;               // the wave's replay clock when this lane's orbit was popped
   uint32_t replay_clock = 0;
   unsigned long long counted_s = 0;   // iterations counted for the orbits pushed by long_tail (see long_retire)
+  unsigned long long skipped_s = 0;   // iterations not made for the samples the interior map retired (mid_pass)
 
   // Carry-over: pick up the queues and orbit slots the previous launch left behind (DrawArgs::carry).
   unsigned long long *const carry = a.carry + (size_t) wave_id * (2u * kCarryWordsPerWave);
@@ -1536,14 +1578,29 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       const int n = (int) __builtin_amdgcn_readfirstlane((uint32_t) (q0_count < 64 ? q0_count : 64));
       const KernelArgs ma = kernel_args();
       const unsigned long long take = uniform_u64((n == 64) ? ~0ull : ((1ull << n) - 1ull));
-      unsigned long long alive;
+      unsigned long long alive, hit;
       uint32_t steps;
+#ifdef CB_BURNING_SHIP
+      const unsigned long long map = 0ull;  // (the map is the Mandelbrot set's)
+#else
+      const unsigned long long map = reinterpret_cast<unsigned long long>(ma->interior_map);
+#endif
       mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
-               (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
+               (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps, map, ma->interior_shift,
+               ma->interior_cols, ma->interior_rows, hit);
+      alive = uniform_u64(alive);
+      hit = uniform_u64(hit);
       q0_head = (q0_head + n) & (kQ0Cap - 1);
       q0_count -= n;
       n_iterate += steps;
       n_too_fast += (unsigned long long) __popcll(take & ~alive);  // escaped before min_iter
+      if (hit != 0ull) {  // samples of cells proven never-escaping: the reference iterates them to max_iter (cudabrot.cu:339)
+        const uint32_t n_hit = (uint32_t) __popcll(hit & alive);
+        n_never += n_hit;
+        skipped_s += (unsigned long long) n_hit * (unsigned long long) (uint32_t) (max_iter - long_start);
+        if ((hit & ~alive) != 0ull) status |= CB_STATUS_INTERIOR_MAP;
+        alive &= ~hit;
+      }
       q1_count += __popcll(alive);
       if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
       if (kTimed) t_mid += __builtin_amdgcn_s_memtime() - t0;
@@ -1697,7 +1754,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     pl[29 * 64] = (unsigned long long) __double_as_longlong(po.i);
     pl[30 * 64] = (unsigned long long) p_start | ((unsigned long long) (lane_in(pact) ? 1u : 0u) << 32);
   }
-  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
+  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo) + skipped_s;
   const unsigned long long counted_total = wave_sum((unsigned long long) counted) + counted_s;
   if (ea->counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(ea->counters);

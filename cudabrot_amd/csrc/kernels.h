@@ -165,6 +165,12 @@ struct DrawArgs {
   int n_channels;
   int chan_min[CB_MAX_CHANNELS], chan_max[CB_MAX_CHANNELS];
   unsigned long long plane_pixels;
+  // The interior map (tools/interior_map.c; null: none): one bit per cell of side 2^-level of the c-plane, re in
+  // [-2, 0.5), |im| in [0, 1.25), set where EVERY sample of the cell provably never escapes under the reference's
+  // iteration.  draw_wide_kernel's MID stage looks a survivor of HEAD up and retires a marked one as never-escaping
+  // instead of iterating it until its orbit repeats.  interior_shift = level - 1 (the kernel's coordinates are doubled).
+  const unsigned char *interior_map;
+  uint32_t interior_shift, interior_cols, interior_rows;
 };
 
 constexpr uint32_t kCarryHeaderWords = 8;

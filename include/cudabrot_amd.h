@@ -77,6 +77,7 @@ typedef struct {
 
 #define CB_STATUS_QUEUE_OVERFLOW 1u
 #define CB_STATUS_REPLAY_RUNAWAY 2u
+#define CB_STATUS_INTERIOR_MAP 4u /* a sample of a cell proven never-escaping (interior map) escaped */
 /* Returned (instead of a hipError_t) by cb_renderer_finish and by everything that reads a renderer's histogram
  * or image when cb_counters.status is nonzero: a draw kernel saw one of its internal invariants broken and has
  * lost samples, so the histogram is not a result.  cb_renderer_read_counters still succeeds and shows the flags. */
@@ -283,6 +284,10 @@ const char *cb_debug_knob(const char *name);
  * 0 none yet, 1 draw_wave_kernel (four waves per SIMD), 2 draw_wide_kernel (two waves per SIMD, runs beside the
  * scatter), 3 the lock-step baseline.  The kernels give identical results; tests use this to know what they covered. */
 int cb_debug_last_draw_kernel(void);
+/* The level of the interior map the last cb_draw_buddhabrot call of this process used (cells of side 2^-level of the
+ * c-plane whose samples provably never escape: the draw kernel retires them without iterating; built by `make` as
+ * interior_map.bin beside the library, see tools/interior_map.c), 0 if it used none.  Results do not depend on it. */
+int cb_debug_interior_map_level(void);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 BOX = (-2.0, 2.0, -2.0, 2.0)
+# (skipped_steps -- the iterations NOT made for samples retired early -- is the kernels' own business: the wide kernel
+# also retires the samples of cells proven never-escaping, tests/test_gpu_interior_map.py)
 COUNTER_KEYS = ("samples", "rejected", "never_escaped", "too_fast", "recorded", "iterate_steps",
-                "replay_steps", "increments", "skipped_steps")
+                "replay_steps", "increments")
 WIDE, WAVE = 2, 1
 
 
@@ -75,7 +77,7 @@ def test_wide_kernel_full_iterate_and_burning_ship(cb, oracle, monkeypatch):
     base = render(cb, 512, 512, 500, 20, 4096, 4)
     full = render(cb, 512, 512, 500, 20, 4096, 4, variant=cb.CB_KERNEL_FULL_ITERATE)
     assert full[2] == WIDE and full[1]["skipped_steps"] == 0
-    same(base, full, keys=[k for k in COUNTER_KEYS if k != "skipped_steps"])
+    same(base, full)
     ship = render(cb, 512, 512, 500, 20, 4096, 4, variant=cb.CB_KERNEL_DEFAULT | cb.CB_KERNEL_FLAG_BURNING_SHIP)
     assert ship[2] == WIDE
     ref = oracle.render(512, 512, 500, 20, 4096, 4, burning_ship=True, omp_threads=0)
