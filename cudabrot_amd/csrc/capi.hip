@@ -48,7 +48,7 @@ int device_matrices(const uint32_t **out) {
 }
 
 // The interior map (DrawArgs::interior_map; tools/interior_map.c makes and proves it, `make` builds it beside the
-// library as interior_map.bin): one copy per device, read on first use from CUDABROT_AMD_INTERIOR_MAP or from the
+// library as interior_map.bin): one copy per device, read on first use from the
 // directory of this library / binary (or its cudabrot_amd/ subdirectory).  No file: no map -- the same results, the
 // never-escaping samples at their old price.
 struct InteriorMap {
@@ -61,7 +61,7 @@ bool g_interior_tried[64] = {false};
 int g_interior_level = 0;  // cb_debug_interior_map_level: the level of the map the last launch used (0: none)
 
 FILE *open_interior_map() {
-  if (const char *e = getenv("CUDABROT_AMD_INTERIOR_MAP")) return fopen(e, "rb");
+  if (const char *e = cb_debug_knob("CUDABROT_AMD_INTERIOR_MAP")) return fopen(e, "rb");  // (a test knob: another file)
   Dl_info info;
   if (!dladdr(reinterpret_cast<const void *>(&open_interior_map), &info) || !info.dli_fname) return nullptr;
   std::string dir(info.dli_fname);
