@@ -501,6 +501,7 @@ def main():
         job.step(0)      # drain: every sample drawn in the K steps is complete before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
+    interior_map_level = int(cb.lib.cb_debug_interior_map_level())  # (of the timed launches: the legs below have their own kernels)
     dev_ev[1].record(job.draw_stream_t)
     torch.cuda.synchronize()
     drain_ms = dev_ev[0].elapsed_time(dev_ev[1])
@@ -540,7 +541,8 @@ def main():
         assert total_incr == all_incr, "reduced histogram holds %d increments, the ranks counted %d" % (total_incr, all_incr)
         avg_ms = sum(kernel_ms) / len(kernel_ms)
         avg_flush_ms = sum(flush_ms) / len(flush_ms)
-        # EXECUTED iterations: the reference's count minus what the exact-periodicity check retired early
+        # EXECUTED iterations: the reference's count minus what the exact-periodicity check and the interior map
+        # (cells proven never-escaping) retired early
         iters_per_launch = (loc["iterate_steps"] - loc["skipped_steps"] + loc["replay_steps"]) / args.steps
         incr_per_launch = loc["increments"] / args.steps
         traffic = recorded_traffic(threads * samples_per_thread) if args.config == "C3" else None
@@ -587,6 +589,7 @@ def main():
             "executed_iterations_per_sample": round(
                 (cnt["iterate_steps"] - cnt["skipped_steps"] + cnt["replay_steps"]) / cnt["samples"], 3),
             # the one exchange of the path (after the clock): ranks in the communicator and its wall time
+            "interior_map_level": interior_map_level,
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "histogram_reduce_ms": round(reduce_ms, 3),
             "roofline": {
@@ -610,8 +613,9 @@ def main():
                 "traffic_source": traffic["source"] if traffic else None,
                 "note": "no MFMA: the path has no contraction; 10 ALGORITHMIC flops per z<-z^2+c iteration (the reference's "
                         "loop body, cudabrot.cu:331-336) over the iterations the kernel EXECUTED (counted in-kernel; orbits "
-                        "found exactly periodic are retired early with the identical outcome, so at max_iter=20000 only "
-                        "~13 % of the reference's iterations are executed).  The kernel spends fewer fp64 instructions than "
+                        "found exactly periodic, and samples of parameter cells PROVEN never-escaping -- interior_map_level, "
+                        "tools/interior_map.c -- are retired early with the identical outcome, so at max_iter=20000 only "
+                        "~12 % of the reference's iterations are executed).  The kernel spends fewer fp64 instructions than "
                         "that on most of them: a tested step is 6 fp64 instructions + 1 compare (doubled-coordinate form), "
                         "and the LONG stage -- escape is absorbing, so it tests once per chunk of 60 steps and decides the rare "
                         "sample with |c| next to 2 exactly -- 4.1 per step; it also draws, tests and replays, so `frac` is NOT a "
