@@ -303,8 +303,6 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
   "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
   "s_branch 99f\n\t"
 
-#define CBW_GA(k) "%[a" #k "]"
-#define CBW_GB(k) "%[b" #k "]"
 // the ten bodies: generator A / B alternately, rot = 0 0 4 4 3 3 2 2 1 1 (logical word j in field (j + rot) % 5)
 #define CBW_BODY_A(f0, f1, f2, f3, f4) CBW_BODY("%[a" #f0 "]", "%[a" #f1 "]", "%[a" #f2 "]", "%[a" #f3 "]", "%[a" #f4 "]", "%[ad]")
 #define CBW_BODY_B(f0, f1, f2, f3, f4) CBW_BODY("%[b" #f0 "]", "%[b" #f1 "]", "%[b" #f2 "]", "%[b" #f3 "]", "%[b" #f4 "]", "%[bd]")
@@ -440,17 +438,7 @@ __device__ __forceinline__ Xorwow xorwow_rotated4(const Xorwow &s) {
 
 // ---- MID in one piece (draw_wave.hip, mid_pass): 64 lanes pop c from Q0, re-derive z after HEAD's four
 // iterations, run n_steps more under EXEC, push the survivors' (c, z) to Q1 ------------------------------------
-#define CB_STEP_LIT                                   \
-  "s_bcnt1_i32_b64 %[tmp], exec\n\t"                  \
-  "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
-  "s_add_u32 %[cnt], %[cnt], %[tmp]\n\t"              \
-  "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
-  "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
-  "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"              \
-  "v_mul_f64 %[a], %[r], %[r]\n\t"                    \
-  "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"              \
-  "v_cmpx_nlt_f64_e32 vcc, 0x40300000, %[a]\n\t"
-// the same with the lane count taken behind the step's first instruction (which waits for the EXEC of the compare
+// a tested step with the lane count taken behind its first instruction (which waits for the EXEC of the compare
 // before it anyway)
 #define CBW_MID_STEP                                  \
   "v_mul_f64 %[a], %[i], %[i]\n\t"                    \
@@ -1457,8 +1445,8 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   // loop would also wait, every time round, for the pixel stream's stores of the bursts before (vmcnt counts both).
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
 
-  // ONE stage action per iteration, in the order of precedence REPLAY > HEAD > MID > LONG.  The statements that write
-  // lane registers are executed in EVERY iteration and told by a scalar whether to do anything (head_bodies).
+  // ONE stage action per iteration, in the order of precedence REPLAY > HEAD > MID > LONG (scalar branches: the
+  // scheduler's state is made provably wave-uniform at the top of every iteration).
   for (;;) {
     // the scheduler's state is wave-uniform by construction; readfirstlane makes that provable (scalar registers,
     // scalar branches)
