@@ -108,6 +108,24 @@ const InteriorMap *device_interior_map() {
   return g_interior[dev].d_bits ? &g_interior[dev] : nullptr;
 }
 
+// The map for a launch of the wave-scheduled kernels (their MID stage in its one-piece form looks samples up; the
+// lock-step kernel and the other forms ignore it): where orbits may be retired early at all -- not the Burning Ship,
+// not the full-iterate variants (CUDABROT_AMD_NO_INTERIOR_MAP=1, a test knob: never).
+void attach_interior_map(cb::DrawArgs &a, bool ship, int base_variant) {
+  g_interior_level = 0;
+  if (ship || base_variant == CB_KERNEL_FULL_ITERATE || base_variant == CB_KERNEL_SIMPLE ||
+      cb_debug_knob("CUDABROT_AMD_TIMED_FULL") != nullptr || cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") != nullptr) {
+    return;
+  }
+  if (const InteriorMap *m = device_interior_map()) {
+    a.interior_map = m->d_bits;
+    a.interior_shift = m->level - 1u;
+    a.interior_cols = m->cols;
+    a.interior_rows = m->rows;
+    g_interior_level = (int) m->level;
+  }
+}
+
 // x / delta == x * (1 / delta) bit for bit iff delta is a (normal) power of two.
 bool exact_reciprocal(double delta, double *inv) {
   int e = 0;
@@ -460,19 +478,7 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
   const bool wide = cb::draw_wide_takes(a) && cb_debug_knob("CUDABROT_AMD_NO_WIDE") == nullptr;
   const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
   g_last_draw_kernel = base_variant == CB_KERNEL_SIMPLE ? 3 : (wide ? 2 : 1);
-  g_interior_level = 0;
-  // the interior map: the wide kernel's, where orbits may be retired early at all (CUDABROT_AMD_NO_INTERIOR_MAP=1, a
-  // test knob: never)
-  if (wide && !ship && base_variant != CB_KERNEL_FULL_ITERATE && cb_debug_knob("CUDABROT_AMD_TIMED_FULL") == nullptr &&
-      cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") == nullptr) {
-    if (const InteriorMap *m = device_interior_map()) {
-      a.interior_map = m->d_bits;
-      a.interior_shift = m->level - 1u;
-      a.interior_cols = m->cols;
-      a.interior_rows = m->rows;
-      g_interior_level = (int) m->level;
-    }
-  }
+  attach_interior_map(a, ship, base_variant);
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
       return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));
@@ -538,6 +544,7 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
     int rc = empty_stream_if_nothing_launches(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
+  attach_interior_map(a, ship, base_variant);
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
   g_last_draw_kernel = 1;
   return (int) wave(a, false, reinterpret_cast<hipStream_t>(stream));

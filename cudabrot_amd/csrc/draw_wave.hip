@@ -468,14 +468,22 @@ __device__ __forceinline__ void head_loop(Xorwow &g, uint32_t &samples_left, uin
   "v_fma_f64 %[a], %[r], %[r], -%[a]\n\t"             \
   "v_fma_f64 %[i], " CB_AL "%[r]" CB_AR ", " CB_AL "%[i]" CB_AR ", %[ci]\n\t"             \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"
+// map / shift / cols / rows: the interior map (DrawArgs::interior_map, 0: none; draw_wide.hip's mid_pass has the same
+// lines): the cell of every popped c is looked up while the stage iterates, and a lane whose cell is marked -- proven
+// never-escaping -- is not pushed (`hit`, among the lanes of `take`).
 __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_plus_head,
                                          uint32_t q0_lds, uint32_t n_steps, uint32_t q1_tail,
                                          uint32_t q1_lds, unsigned long long &alive,
-                                         uint32_t &lane_steps) {
+                                         uint32_t &lane_steps, unsigned long long map, uint32_t shift,
+                                         uint32_t cols, uint32_t rows, unsigned long long &hit) {
   static_assert(kQ0Cap == 128 && kQ1Cap == 96, "ring mask, ring length and plane distances below");
-  unsigned long long save;
-  uint32_t cnt, tmp, ctr, slot, wr;
+  unsigned long long save, t64;
+  uint32_t cnt, tmp, ctr, slot, wr, mbit, hitb;
   double cr, ci, r, i, a;
+  map = uniform_u64(map);
+  shift = __builtin_amdgcn_readfirstlane(shift);
+  cols = __builtin_amdgcn_readfirstlane(cols);
+  rows = __builtin_amdgcn_readfirstlane(rows);
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_mov_b64 exec, %[take]\n\t"
@@ -485,7 +493,28 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "ds_read_b64 %[ci], %[slot] offset:1024\n\t"
       "s_mov_b32 %[cnt], 0\n\t"
       "s_mov_b32 %[ctr], %[n]\n\t"
+      "s_mov_b64 %[hit], 0\n\t"
       "s_waitcnt lgkmcnt(0)\n\t"
+      "s_cmp_eq_u64 %[map], 0\n\t"
+      "s_cbranch_scc1 10f\n\t"
+      "v_add_f64 %[a], %[cr], 4.0\n\t"           // column floor((Cr + 4) 2^shift), row floor(|Ci| 2^shift): doubled coordinates
+      "v_ldexp_f64 %[a], %[a], %[shift]\n\t"
+      "v_cmp_le_f64_e32 vcc, 0, %[a]\n\t"
+      "v_cvt_u32_f64 %[slot], %[a]\n\t"
+      "v_ldexp_f64 %[a], |%[ci]|, %[shift]\n\t"
+      "v_cvt_u32_f64 %[wr], %[a]\n\t"
+      "v_cmp_gt_u32_e64 %[t64], %[cols], %[slot]\n\t"
+      "s_and_b64 vcc, vcc, %[t64]\n\t"
+      "v_cmp_gt_u32_e64 %[t64], %[rows], %[wr]\n\t"
+      "s_and_b64 vcc, vcc, %[t64]\n\t"
+      "v_mad_u32_u24 %[slot], %[wr], %[cols], %[slot]\n\t"
+      "v_and_b32 %[mbit], 7, %[slot]\n\t"
+      "v_lshrrev_b32 %[slot], 3, %[slot]\n\t"
+      "v_mov_b32 %[hitb], 0\n\t"
+      "s_mov_b64 exec, vcc\n\t"
+      "global_load_ubyte %[hitb], %[slot], %[map]\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "10:\n\t"
       // HEAD's iterations again, from z = c (first product: I*I with I = ci)
       "v_mul_f64 %[a], %[ci], %[ci]\n\t"
       "v_fma_f64 %[a], %[cr], %[cr], -%[a]\n\t"
@@ -502,6 +531,16 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_cbranch_scc1 1b\n\t"
       "2:\n\t"
       "s_mov_b64 %[alive], exec\n\t"
+      "s_cmp_eq_u64 %[map], 0\n\t"
+      "s_cbranch_scc1 11f\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %[take]\n\t"
+      "v_lshrrev_b32 %[hitb], %[mbit], %[hitb]\n\t"
+      "v_and_b32 %[hitb], 1, %[hitb]\n\t"
+      "v_cmp_ne_u32_e32 vcc, 0, %[hitb]\n\t"
+      "s_mov_b64 %[hit], vcc\n\t"
+      "s_andn2_b64 exec, %[alive], vcc\n\t"
+      "11:\n\t"
       "v_mbcnt_lo_u32_b32 %[slot], exec_lo, 0\n\t"
       "v_mbcnt_hi_u32_b32 %[slot], exec_hi, %[slot]\n\t"
       "v_add_u32 %[slot], %[tail], %[slot]\n\t"          // < 96 + 64
@@ -516,9 +555,9 @@ __device__ __forceinline__ void mid_pass(unsigned long long take, uint32_t lane_
       "s_nop 4\n\t"
       : [alive] "=&s"(alive), [cnt] "=&s"(cnt), [save] "=&s"(save), [tmp] "=&s"(tmp), [ctr] "=&s"(ctr),
         [slot] "=&v"(slot), [wr] "=&v"(wr), [cr] "=&v"(cr), [ci] "=&v"(ci), [a] "=&v"(a), [r] "=&v"(r),
-        [i] "=&v"(i)
+        [i] "=&v"(i), [hit] "=&s"(hit), [t64] "=&s"(t64), [mbit] "=&v"(mbit), [hitb] "=&v"(hitb)
       : [take] "s"(take), [lph] "v"(lane_plus_head), [q0] "s"(q0_lds), [n] "s"(n_steps),
-        [tail] "v"(q1_tail), [q1] "s"(q1_lds)
+        [tail] "v"(q1_tail), [q1] "s"(q1_lds), [map] "s"(map), [shift] "s"(shift), [cols] "s"(cols), [rows] "s"(rows)
       : "vcc", "scc", "memory");
   lane_steps = cnt;
 }
@@ -1427,6 +1466,7 @@ draw_wave_kernel(DrawArgs a) {
   double seen_r[kOrbitsPerLane] = {0, 0}, seen_i[kOrbitsPerLane] = {0, 0};  // periodicity check
   int l_rem[kOrbitsPerLane] = {0, 0};  // iterations left before max_iter; 0 = idle
   uint32_t skip_lo = 0, skip_hi = 0;  // per lane, 64 bits: iterations the periodicity check made unnecessary
+  unsigned long long skipped_s = 0;   // ... and the interior map (mid_pass)
   uint32_t over = 0;                  // per lane: iterations the sparse LONG chunks counted beyond an escape
   // REPLAY lane state
   Orbit po = {0, 0, 0, 0};
@@ -1784,14 +1824,29 @@ draw_wave_kernel(DrawArgs a) {
       const KernelArgs ma = fresh_args();
       if (kFastHead && ma->fast_mid) {
         const unsigned long long take = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-        unsigned long long alive;
+        unsigned long long alive, hit;
         uint32_t steps;
+#ifdef CB_BURNING_SHIP
+        const unsigned long long map = 0ull;  // (the map is the Mandelbrot set's)
+#else
+        const unsigned long long map = reinterpret_cast<unsigned long long>(ma->interior_map);
+#endif
         mid_pass(take, (uint32_t) q0_head + (uint32_t) lane_id(), q0_lds, (uint32_t) ma->mid_steps,
-                 (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps);
+                 (uint32_t) q1_wrap(q1_head + q1_count), q1_lds, alive, steps, map, ma->interior_shift,
+                 ma->interior_cols, ma->interior_rows, hit);
+        alive = uniform_u64(alive);
+        hit = uniform_u64(hit);
         q0_head = (q0_head + n) & (kQ0Cap - 1);
         q0_count -= n;
         f_steps += steps;
         f_too_fast += (uint32_t) __popcll(take & ~alive);  // escaped before min_iter
+        if (hit != 0ull) {  // samples of cells proven never-escaping: the reference iterates them to max_iter (cudabrot.cu:339)
+          const uint32_t n_hit = (uint32_t) __popcll(hit & alive);
+          n_never += n_hit;
+          skipped_s += (unsigned long long) n_hit * (unsigned long long) (uint32_t) (ma->max_iter - ma->long_start);
+          if ((hit & ~alive) != 0ull) status |= CB_STATUS_INTERIOR_MAP;
+          alive &= ~hit;
+        }
         q1_count += __popcll(alive);
         if (q1_count > kQ1Cap) status |= CB_STATUS_QUEUE_OVERFLOW;
         if (kTimed) t_head += __builtin_amdgcn_s_memtime() - t0;
@@ -2025,7 +2080,7 @@ draw_wave_kernel(DrawArgs a) {
     pl[18 * 64] = (unsigned long long) p_tag | ((unsigned long long) (p_real ? 1u : 0u) << 32) |
                   ((unsigned long long) (p_direct ? 1u : 0u) << 33);
   }
-  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo);
+  const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo) + skipped_s;
   const unsigned long long over_total = wave_sum((unsigned long long) over);
   if (a.counters && lane_id() == 0) {
     unsigned long long *c = reinterpret_cast<unsigned long long *>(a.counters);
