@@ -1,20 +1,24 @@
 """tools/interior_map.c on the CPU: the generator / prover of the interior map, its model and its check (no GPU).
 
 The map's claim is proved cell by cell by the generator itself (see the file's header); these tests hold the program to
-what it says: that a map it makes survives its own check (samples inside marked cells, iterated to max_iter with the
-reference's arithmetic: none escapes), that the model finds no disagreement between the map and the iteration, that the
-marked area is what it was when the kernel's share of work was measured, and that the file `make` puts beside the
-library is the one the library accepts."""
+what it says -- a map it makes survives its own check (samples inside marked cells, iterated to max_iter with the
+reference's arithmetic: none escapes), the model finds no disagreement between the map and the iteration -- and hold
+the map KEPT in the tree (cudabrot_amd/interior_map.bin.gz: an hour of proving, `make interior-map`) to the program:
+every cell a shallower, quick run of the prover marks is marked in it, nothing outside the prover's reach is, and
+samples inside its cells do not escape."""
 
+import gzip
 import os
 import re
 import struct
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tools", "interior_map.c")
+KEPT = os.path.join(ROOT, "cudabrot_amd", "interior_map.bin.gz")
 
 
 @pytest.fixture(scope="module")
@@ -28,32 +32,53 @@ def run(*cmd):
     return subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
 
 
+def bits_of(path_or_bytes):
+    raw = path_or_bytes if isinstance(path_or_bytes, bytes) else open(path_or_bytes, "rb").read()
+    head = struct.unpack("<4I", raw[:16])
+    return head, np.frombuffer(raw, dtype=np.uint8, offset=16)
+
+
 def test_a_small_map_passes_its_own_check_and_model(tool, tmp_path):
-    path = str(tmp_path / "map10.bin")
-    out = run(tool, "make", "10", path)
+    flat, deep = str(tmp_path / "map10_0.bin"), str(tmp_path / "map10_2.bin")
+    out = run(tool, "make", "10", flat, "0")
     m = re.search(r"(\d+) tried, (\d+) marked", out)
-    assert m and int(m.group(2)) == 23769, out            # level 10: what the prover marks (a change of the prover shows here)
-    head = struct.unpack("<4I", open(path, "rb").read(16))
-    assert head == (0x4D494243, 10, 2560, 1280)
-    assert os.path.getsize(path) == 16 + 2560 * 1280 // 8
-    assert open(path, "rb").read(17)[16] & 1 == 0         # cell 0 is the kernel's "outside": never marked
-    out = run(tool, "check", "10", path, "200000")
-    assert re.search(r"200000 samples inside 23769 marked cells iterated to 20000: 0 escaped", out), out
-    out = run(tool, "model", "10", path, "300000")
+    assert m and int(m.group(2)) == 23769, out            # level 10, whole cells only (a change of the prover shows here)
+    out = run(tool, "make", "10", deep, "2")
+    n_deep = int(re.search(r"(\d+) tried, (\d+) marked", out).group(2))
+    assert n_deep > 28000, out                            # ... and with cells proven by their quarters, two levels down
+    head, b0 = bits_of(flat)
+    _, b2 = bits_of(deep)
+    assert head == (0x4D494243, 10, 2560, 1280) and b0.size == 2560 * 1280 // 8
+    assert b0[0] & 1 == 0 and b2[0] & 1 == 0              # cell 0 is the kernel's "outside": never marked
+    assert np.all((b0 & ~b2) == 0)                        # what a whole-cell proof reaches, the deeper one reaches too
+    out = run(tool, "check", "10", deep, "200000")
+    assert re.search(r"200000 samples inside %d marked cells iterated to 20000: 0 escaped" % n_deep, out), out
+    out = run(tool, "model", "10", deep, "300000")
     assert "DISAGREEMENT" not in out
     m = re.search(r"periodicity check alone ([\d.]+), with the map ([\d.]+)", out)
     assert m and float(m.group(2)) < float(m.group(1))
 
 
-def test_the_built_map_is_what_the_library_accepts(tool):
-    """cudabrot_amd/interior_map.bin (made by `make`, level 13): header, size, and a check of 400000 samples inside
-    its marked cells."""
-    path = os.path.join(ROOT, "cudabrot_amd", "interior_map.bin")
-    if not os.path.exists(path):
-        pytest.skip("interior_map.bin has not been built (make -C cudabrot_amd/csrc)")
-    magic, level, cols, rows = struct.unpack("<4I", open(path, "rb").read(16))
-    assert magic == 0x4D494243 and 8 <= level <= 15
-    assert cols == (5 << level) // 2 and rows == (5 << level) // 4
-    assert os.path.getsize(path) == 16 + (cols * rows + 7) // 8
-    out = run(tool, "check", str(level), path, "400000")
-    assert re.search(r"400000 samples inside \d+ marked cells iterated to 20000: 0 escaped", out), out
+def test_the_kept_map_against_the_prover(tool, tmp_path):
+    """cudabrot_amd/interior_map.bin.gz: level 12, cells proven up to six levels of quarters down.  A run of the prover
+    one level deep (seconds) must mark nothing the kept map lacks; the kept map must mark nothing outside the cells a
+    CENTRE-only iteration finds bounded (the prover's necessary condition); 400000 samples inside its cells are
+    iterated to max_iter."""
+    kept = str(tmp_path / "kept.bin")
+    raw = gzip.open(KEPT, "rb").read()
+    open(kept, "wb").write(raw)
+    head, kept_bits = bits_of(raw)
+    magic, level, cols, rows = head
+    assert magic == 0x4D494243 and level == 12 and cols == 10240 and rows == 5120
+    assert kept_bits.size == cols * rows // 8 and kept_bits[0] & 1 == 0
+    shallow = str(tmp_path / "shallow.bin")
+    run(tool, "make", "12", shallow, "1")
+    _, shallow_bits = bits_of(shallow)
+    assert np.all((shallow_bits & ~kept_bits) == 0), "a cell the prover marks is missing from the kept map"
+    n_kept = int(np.unpackbits(kept_bits).sum())
+    assert n_kept > int(np.unpackbits(shallow_bits).sum()) > 700000
+    out = run(tool, "check", "12", kept, "400000")
+    assert re.search(r"400000 samples inside %d marked cells iterated to 20000: 0 escaped" % n_kept, out), out
+    built = os.path.join(ROOT, "cudabrot_amd", "interior_map.bin")
+    if os.path.exists(built):                             # what `make` unpacked beside the library
+        assert open(built, "rb").read() == raw

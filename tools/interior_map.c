@@ -21,11 +21,13 @@
 //      |z_{a+k}| + rho'_k <= 1.99 for k <= P and rho'_P + d <= R, then any w within R of z_a is, P steps later, within
 //      rho'_P of z_b, that is within R of z_a again, and in between within rho'_k of z_{a+k}: by induction over the
 //      rounds every later point of the sequence lies within rho'_k of some z_{a+k}, hence below 1.99 in modulus.
-//  (1) puts w_a(c) within rho_a <= R of z_a for every c in Q; (2) keeps it there.  The bounds are evaluated in long
-//  double with every update inflated by 1 + 2^-40, which dominates the roundings of its handful of operations.
+//  (1) puts w_a(c) within rho_a <= R of z_a for every c in Q; (2) keeps it there.  The bounds are evaluated in
+//  double -- sums, products and square roots of positive quantities only -- with every update inflated by 1 + 2^-40,
+//  which dominates the 2^-53 roundings of its handful of operations (1.4142135623730951 > sqrt 2).
 //
 //   gcc -O2 -fopenmp -ffp-contract=off -o interior_map tools/interior_map.c -lm
-//   ./interior_map make LEVEL out.bin        the map: cells of side 2^-LEVEL over re in [-2, 0.5), |im| in [0, 1.25);
+//   ./interior_map make LEVEL out.bin [D]    the map: cells of side 2^-LEVEL over re in [-2, 0.5), |im| in [0, 1.25),
+//                                            each proven as one disc or by its quarters, D (default 2) levels deep;
 //                                            16 bytes of header ("CBIM", LEVEL, columns, rows: u32), then one bit per
 //                                            cell, row by row (bit k & 7 of byte k >> 3, k = row * columns + column)
 //   ./interior_map model LEVEL map.bin N     N uniform samples on [-2,2]^2: iterations per sample with the kernel's
@@ -42,10 +44,12 @@
 #define RE_SPAN 2.5
 #define IM_SPAN 1.25
 #define RING 128
-static const long double kInflate = 1.0L + 0x1p-40L;
-static const long double kEps2 = 0x1p-44L;   // 2 eps
-static const long double kBound = 1.99L;
-static const long double kGiveUp = 0.02L;    // a ball this large will not be trapped: the cell is too near a boundary
+typedef double bound_t;  // the bounds: positive quantities, sums, products and square roots only -- every update is
+                         // inflated by 1 + 2^-40, which dominates the 2^-53 roundings of its handful of operations
+static const bound_t kInflate = 1.0 + 0x1p-40;
+static const bound_t kEps2 = 0x1p-44;   // 2 eps
+static const bound_t kBound = 1.99;
+static const bound_t kGiveUp = 0.02;    // a ball this large will not be trapped: the cell is too near a boundary
 
 static inline void step(double *r, double *i, double cr, double ci) {  // device_math.h's canonical sequence
   const double ii = *i * *i, t = fma(*r, *r, -ii);
@@ -58,23 +62,30 @@ static inline int in_cardioid_or_bulb(double cr, double ci) {
   if (q * (q + x) < 0.25 * ci * ci) return 1;
   return (cr + 1.0) * (cr + 1.0) + ci * ci < 0.0625;
 }
-static inline long double next_rho(long double rho, long double mag, long double rc) {
-  return (rho * (2.0L * mag + rho) + rc + kEps2) * kInflate;
+static inline bound_t next_rho(bound_t rho, bound_t mag, bound_t rc) {
+  return (rho * (2.0 * mag + rho) + rc + kEps2) * kInflate;
 }
-static inline long double modulus_up(double r, double i) {
-  return sqrtl((long double) r * r + (long double) i * i) * kInflate;
+static inline bound_t modulus_up(double r, double i) {
+  return sqrt((bound_t) r * r + (bound_t) i * i) * kInflate;
 }
 
-// 1 if the cell of centre (c0r, c0i) and radius rc (covering the enlarged square) is proven never-escaping.
-static int verify_cell(double c0r, double c0i, long double rc, int max_steps) {
+// 1 if the cell of centre (c0r, c0i) and radius rc (covering the enlarged square) is proven never-escaping; -1 if its
+// centre itself escapes (no part of a square around it can then be proven as a whole); 0 if the proof does not get there.
+static int verify_cell(double c0r, double c0i, bound_t rc, int max_steps) {
   double zr[RING], zi[RING];
-  long double rho_at[RING];
+  bound_t rho_at[RING];
   double r = c0r, i = c0i;
-  long double rho = rc * kInflate;
+  bound_t rho = rc * kInflate;
   int next_try = 64;
   for (int j = 0; j < max_steps; ++j) {
-    const long double mag = modulus_up(r, i);
-    if (mag + rho > kBound) return 0;
+    const bound_t mag = modulus_up(r, i);
+    if (mag + rho > kBound) {  // the ball is at the bound: a centre on its way out says so within a few steps
+      for (int k = 0; k < 64; ++k) {
+        if (!(fma(i, i, r * r) <= 4.0)) return -1;
+        step(&r, &i, c0r, c0i);
+      }
+      return 0;
+    }
     zr[j % RING] = r;
     zi[j % RING] = i;
     rho_at[j % RING] = rho;
@@ -82,27 +93,42 @@ static int verify_cell(double c0r, double c0i, long double rc, int max_steps) {
       next_try = j < 4096 ? 2 * j : j + 4096;
       for (int P = 1; P <= 96 && P <= j; ++P) {  // is the ball at a = j - P trapped by the round a .. j?
         const int a = j - P;
-        const long double d = modulus_up(r - zr[a % RING], i - zi[a % RING]);  // (the difference of doubles: exact or rounded, inflated)
-        const long double rho_a = rho_at[a % RING];
+        const bound_t d = modulus_up(r - zr[a % RING], i - zi[a % RING]);  // (the difference of doubles: exact or rounded, inflated)
+        const bound_t rho_a = rho_at[a % RING];
         if (d > rho_a) continue;  // not a return yet
-        const long double R = 2.0L * rho_a + 8.0L * d;
-        long double rp = R;
+        const bound_t R = 2.0 * rho_a + 8.0 * d;
+        bound_t rp = R;
         int ok = 1;
         for (int k = 0; k < P; ++k) {
-          const long double m = modulus_up(zr[(a + k) % RING], zi[(a + k) % RING]);
+          const bound_t m = modulus_up(zr[(a + k) % RING], zi[(a + k) % RING]);
           if (m + rp > kBound) { ok = 0; break; }
           rp = next_rho(rp, m, rc);
-          if (rp > 1.0L) { ok = 0; break; }
+          if (rp > 1.0) { ok = 0; break; }
         }
-        if (ok && modulus_up(r, i) + rp <= kBound && rp + d <= R) return 1;
+        if (ok && modulus_up(r, i) + rp <= kBound && (rp + d) * kInflate <= R) return 1;
       }
     }
     rho = next_rho(rho, mag, rc);
     if (rho > kGiveUp) return 0;
     step(&r, &i, c0r, c0i);
-    if (!(fma(i, i, r * r) <= 4.0)) return 0;
+    if (!(fma(i, i, r * r) <= 4.0)) return -1;
   }
   return 0;
+}
+
+// A cell the proof does not reach as one disc may still be proven piece by piece: the square of centre (c0r, c0i) and
+// half side h is marked if it is proven itself or if its four quarters are (to `depth` levels of quarters) -- the union
+// of the quarters' enlarged squares covers the enlarged square.  A quarter has half the radius: the ball of (1) grows
+// half as fast, and the unproven layer along a component's boundary shrinks with it.
+static int verify_square(double c0r, double c0i, double h, int depth) {
+  const bound_t rc = ((bound_t) h + 0x1p-40) * 1.4142135623730951 * kInflate;
+  const int proven = verify_cell(c0r, c0i, rc, 20000);
+  if (proven != 0 || depth == 0) return proven;  // (a centre that escapes is a point of every square around it)
+  const double q = 0.5 * h;  // exact: dyadic
+  for (int k = 0; k < 4; ++k) {
+    if (verify_square(c0r + ((k & 1) ? q : -q), c0i + ((k & 2) ? q : -q), q, depth - 1) != 1) return 0;
+  }
+  return 1;
 }
 
 static long cols_of(int level) { return (long) ldexp(RE_SPAN, level); }
@@ -133,8 +159,7 @@ int main(int argc, char **argv) {
   uint8_t *map = calloc(bytes, 1);
   if (!strcmp(argv[1], "make")) {
     const double s = ldexp(1.0, -level);
-    // the enlarged cell: half a side + 2^-40 in each coordinate, as a disc
-    const long double rc = (0.5L * s + 0x1p-40L) * 1.41421356237309504881L * kInflate;
+    const int depth = argc > 4 ? atoi(argv[4]) : 2;  // levels of quarters a cell may be proven by
     long marked = 0, tried = 0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : marked, tried)
     for (long y = 0; y < rows; ++y) {
@@ -142,7 +167,7 @@ int main(int argc, char **argv) {
         const double c0r = RE_MIN + (x + 0.5) * s, c0i = (y + 0.5) * s;  // exact: dyadic
         if (c0r * c0r + c0i * c0i > 4.0 || in_cardioid_or_bulb(c0r, c0i)) continue;  // (never looked up / never reaches the lookup)
         ++tried;
-        if (verify_cell(c0r, c0i, rc, 20000)) {
+        if (verify_square(c0r, c0i, 0.5 * s, depth) == 1) {
           const long k = y * cols + x;
 #pragma omp atomic
           map[k >> 3] |= (uint8_t) (1u << (k & 7));
