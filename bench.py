@@ -609,6 +609,12 @@ def main():
                 # own duration (avg_launch_ms) is longer although the step is shorter
                 "step_frac": round(iters_per_launch * FLOPS_PER_ITERATION / (elapsed / args.steps) / 1e12
                                    / PEAK_FP64_VECTOR_TFLOPS, 4),
+                # the flops of the iterations the REFERENCE makes for the same samples (iterations_per_sample, counted
+                # in-kernel) over the whole step: above 1 means the result arrives faster than an ideal fp64 machine
+                # could iterate the reference's orbits -- what the exact early-outs (periodicity, interior map) buy;
+                # not a utilisation
+                "reference_work_step_frac": round((loc["iterate_steps"] + loc["replay_steps"]) / args.steps * FLOPS_PER_ITERATION
+                                                  / (elapsed / args.steps) / 1e12 / PEAK_FP64_VECTOR_TFLOPS, 4),
                 "traffic": traffic["draw"] if traffic else None,
                 "traffic_source": traffic["source"] if traffic else None,
                 "note": "no MFMA: the path has no contraction; 10 ALGORITHMIC flops per z<-z^2+c iteration (the reference's "
