@@ -77,6 +77,18 @@ def test_the_kept_map_against_the_prover(tool, tmp_path):
     assert np.all((shallow_bits & ~kept_bits) == 0), "a cell the prover marks is missing from the kept map"
     n_kept = int(np.unpackbits(kept_bits).sum())
     assert n_kept > int(np.unpackbits(shallow_bits).sum()) > 700000
+    # a necessary condition, checked for EVERY marked cell: its centre's orbit stays below 1.99 in modulus (numpy's
+    # complex arithmetic rounds differently from the reference's sequence; the proof's bound has the room)
+    marked = np.flatnonzero(np.unpackbits(kept_bits, bitorder="little"))
+    assert marked.size == n_kept
+    s = 2.0 ** -level
+    c = (-2.0 + (marked % cols + 0.5) * s) + 1j * ((marked // cols + 0.5) * s)
+    z = c.copy()
+    worst = 0.0
+    for _ in range(400):
+        z = z * z + c
+        worst = max(worst, float(np.abs(z).max()))
+    assert worst < 1.99, worst
     out = run(tool, "check", "12", kept, "400000")
     assert re.search(r"400000 samples inside %d marked cells iterated to 20000: 0 escaped" % n_kept, out), out
     built = os.path.join(ROOT, "cudabrot_amd", "interior_map.bin")
