@@ -12,12 +12,14 @@
 //   HEAD    software-pipelined: the draw of sample n+1 (integer chain) is interleaved, instruction by instruction,
 //           with the cardioid / bulb test and the four iterations of sample n (fp64 chain); A and B alternate.
 //           EXEC stays full (the generator must advance in every lane), the survivors are tracked in scalar masks;
-//   MID     as in draw_wave.hip (one chain; 5 % of the instructions);
+//   MID     as in draw_wave.hip (one chain; 5 % of the instructions) -- and the place where a survivor of HEAD is
+//           looked up in the interior map (DrawArgs::interior_map, tools/interior_map.c): a sample of a cell PROVEN
+//           never-escaping is retired here instead of costing the LONG stage ~2000 iterations;
 //   LONG    FOUR orbits per lane, interleaved instruction by instruction (escape test once per chunk);
 //   REPLAY  software-pipelined: the pixel of point n is formed and stored while point n+1 is computed; a lane's
 //           state between bursts is "z_n computed, not yet recorded".
 //
-// Launched for: a scatter workspace of one level (canvases of up to 1024 tiles), one channel, the usual stage
+// Launched for: a scatter workspace of one level (canvases of up to 1024 tiles) or a chunked one, one channel, the usual stage
 // split with min_iter == the start of the LONG stage (every BASELINE config with the default -c 20), a carry
 // buffer, n_threads a multiple of 512.  Everything else is draw_wave_kernel's (capi.hip picks; same results).
 //
