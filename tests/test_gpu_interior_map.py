@@ -62,6 +62,45 @@ def test_the_map_is_built_loaded_and_used(cb, oracle, monkeypatch):
         assert with_map[1][k] == ref[1][k], (k, with_map[1][k], ref[1][k])
 
 
+def test_without_the_file_or_with_a_wrong_one_nothing_changes_but_the_work(cb, tmp_path, monkeypatch):
+    """The library finds the map beside itself; a missing file, or one that is not a map, leaves the draw kernel as it
+    was before there was one (CUDABROT_AMD_INTERIOR_MAP: a test knob naming another file; read once per device and
+    process, hence the subprocesses)."""
+    import json
+    import subprocess
+    import sys
+
+    prog = (
+        "import json, numpy as np, cudabrot_amd as cb\n"
+        "dims = cb.FractalDimensions.make(256, 256)\n"
+        "with cb.Renderer(dims, cb.IterationControl(1000, 20), n_threads=4096) as r:\n"
+        "    r.render_passes(4)\n"
+        "    h = r.read_histogram(); c = r.read_counters().as_dict()\n"
+        "print(json.dumps({'level': cb.lib.cb_debug_interior_map_level(), 'sum': int(h.sum()), 'crc': int(np.bitwise_xor.reduce(h.ravel() * np.arange(1, h.size + 1, dtype=np.uint64))),"
+        " 'never': c['never_escaped'], 'skipped': c['skipped_steps'], 'iterate': c['iterate_steps'], 'status': c['status']}))\n"
+    )
+    bad = tmp_path / "not_a_map.bin"
+    bad.write_bytes(b"CBIM" + bytes(100))
+
+    def run(path):
+        env = dict(__import__("os").environ, CUDABROT_AMD_DEBUG="1")
+        if path is not None:
+            env["CUDABROT_AMD_INTERIOR_MAP"] = str(path)
+        out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True)
+        return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
+
+    with_map, _ = run(None)
+    missing, _ = run(tmp_path / "no_such_file.bin")
+    wrong, err = run(bad)
+    assert with_map["level"] == built_level() and missing["level"] == 0 and wrong["level"] == 0
+    assert "interior map" in err
+    for other in (missing, wrong):
+        assert other["status"] == 0
+        for k in ("sum", "crc", "never", "iterate"):
+            assert other[k] == with_map[k], k
+        assert other["skipped"] < with_map["skipped"]
+
+
 def test_ten_billion_samples_against_full_iteration(cb):
     """C3 (4096^2, max_iter 20000, 262144 subsequences), 768 passes = 1.0e10 samples: the product against
     CB_KERNEL_FULL_ITERATE, which retires nothing early."""
