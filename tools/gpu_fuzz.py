@@ -218,6 +218,8 @@ def main():
         try:
             if "heavy" in t:
                 got_d, gc = render(t, cb.CB_KERNEL_DEFAULT, on_device=True)
+                if cb.lib.cb_debug_last_draw_kernel() == 2:
+                    wide_trials[0] += 1
                 direct = dict(t, workspace="none", carry="none", two_level=False)
                 want_d, wc = render(direct, cb.CB_KERNEL_DEFAULT, on_device=True)
                 same = bool(torch.equal(got_d, want_d))
