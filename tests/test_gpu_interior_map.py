@@ -46,7 +46,7 @@ def same(a, b):
 
 
 def test_the_map_is_built_loaded_and_used(cb, oracle, monkeypatch):
-    """`make` builds interior_map.bin beside the library (level 12, proven eight levels of quarters deep); the wide kernel uses it and skips more iterations
+    """`make` builds interior_map.bin beside the library (level 12, proven nine levels of quarters deep); the wide kernel uses it and skips more iterations
     than the periodicity check alone -- with the oracle's histogram and counters."""
     args = (512, 512, 2000, 8192, 8)
     with_map = render(cb, *args)
