@@ -24,6 +24,8 @@ CB_KERNEL_FULL_ITERATE = 3
 CB_TONE_AUTO, CB_TONE_LUT, CB_TONE_THRESHOLDS = 0, 1, 2
 CB_KERNEL_FLAG_BURNING_SHIP = 0x100
 CB_KERNEL_FLAG_DRAIN = 0x200
+# cb_counters.status bits (include/cudabrot_amd.h)
+CB_STATUS_QUEUE_OVERFLOW, CB_STATUS_REPLAY_RUNAWAY, CB_STATUS_INTERIOR_MAP, CB_STATUS_CARRY_FOREIGN = 1, 2, 4, 8
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <string>
@@ -47,83 +48,104 @@ int device_matrices(const uint32_t **out) {
   return 0;
 }
 
-// The interior map (DrawArgs::interior_map; tools/interior_map.c makes and proves it, `make` builds it beside the
-// library as interior_map.bin): one copy per device, read on first use from the
-// directory of this library / binary (or its cudabrot_amd/ subdirectory).  No file: no map -- the same results, the
-// never-escaping samples at their old price.
-struct InteriorMap {
-  const unsigned char *d_bits;
+// ---- the interior map: data that decides what the kernels compute --------------------------------------------------
+//
+// One bit per cell of side 2^-level of the c-plane: every sample of a marked cell provably never escapes (made and PROVEN
+// on the CPU by tools/interior_map.c; DrawArgs::interior_map).  It is EMBEDDED in this library and in the binary (maps.S:
+// .incbin of the file `make` unpacks and whose sha256 it checks against the digest kept in the tree) -- there is no file
+// to find, lose or swap at run time.  One copy per device, made on first use.  CUDABROT_AMD_INTERIOR_MAP=<file> (a test
+// knob, behind CUDABROT_AMD_DEBUG=1) takes another map of the same format -- header, level and EXACT length are checked;
+// anything else is an error, never a fallback.
+extern "C" {
+extern const unsigned char cb_embedded_interior_map[], cb_embedded_interior_map_end[];
+}
+
+enum MapKind { kMapInterior = 0, kMapKinds };
+struct DeviceMap {
+  const unsigned char *d_bytes;
   uint32_t level, cols, rows;
 };
-std::mutex g_interior_mutex;
-InteriorMap g_interior[64];
-bool g_interior_tried[64] = {false};
-int g_interior_level = 0;  // cb_debug_interior_map_level: the level of the map the last launch used (0: none)
+std::mutex g_map_mutex;
+DeviceMap g_maps[64][kMapKinds];
+int g_map_state[64][kMapKinds] = {{0}};  // 0: not tried, 1: there, -1: failed (reported once)
+std::atomic<int> g_interior_level{0};    // cb_debug_interior_map_level: the level of the map the last launch used (0: none)
 
-FILE *open_interior_map() {
-  if (const char *e = cb_debug_knob("CUDABROT_AMD_INTERIOR_MAP")) return fopen(e, "rb");  // (a test knob: another file)
-  Dl_info info;
-  if (!dladdr(reinterpret_cast<const void *>(&open_interior_map), &info) || !info.dli_fname) return nullptr;
-  std::string dir(info.dli_fname);
-  const size_t slash = dir.rfind('/');
-  dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-  for (const char *rel : {"/interior_map.bin", "/cudabrot_amd/interior_map.bin"}) {
-    if (FILE *f = fopen((dir + rel).c_str(), "rb")) return f;
+// header: magic, level, columns, rows (u32 each); then the payload, whose length the header implies
+bool parse_map(MapKind, const unsigned char *bytes, size_t n, DeviceMap *out, size_t *payload) {
+  if (n < 16) return false;
+  uint32_t h[4];
+  memcpy(h, bytes, 16);
+  const uint32_t level = h[1];
+  if (h[0] != 0x4d494243u /* "CBIM" */ || level < 8u || level > 15u || h[2] != (5u << level) / 2u ||
+      h[3] != (5u << level) / 4u) {  // 2.5 and 1.25 * 2^level
+    return false;
   }
-  return nullptr;
+  *payload = ((size_t) h[2] * h[3] + 7) / 8;
+  if (n != 16 + *payload) return false;  // not a byte more or less
+  *out = DeviceMap{nullptr, level, h[2], h[3]};
+  return true;
 }
 
-const InteriorMap *device_interior_map() {
+const DeviceMap *device_map(MapKind kind) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(g_interior_mutex);
-  if (!g_interior_tried[dev]) {
-    g_interior_tried[dev] = true;
-    g_interior[dev] = InteriorMap{nullptr, 0u, 0u, 0u};
-    if (FILE *f = open_interior_map()) {
-      uint32_t header[4] = {0, 0, 0, 0};
-      std::vector<unsigned char> bits;
-      bool ok = fread(header, 1, 16, f) == 16 && header[0] == 0x4d494243u && header[1] >= 8u && header[1] <= 15u &&
-                header[2] == (5u << header[1]) / 2u && header[3] == (5u << header[1]) / 4u;  // 2.5 and 1.25 * 2^level
-      if (ok) {
-        const size_t bytes = ((size_t) header[2] * header[3] + 7) / 8;
-        bits.resize(bytes);
-        ok = fread(bits.data(), 1, bytes, f) == bytes;
+  std::lock_guard<std::mutex> lock(g_map_mutex);
+  if (g_map_state[dev][kind] == 0) {
+    g_map_state[dev][kind] = -1;
+    const unsigned char *bytes = cb_embedded_interior_map;
+    size_t n = (size_t) (cb_embedded_interior_map_end - cb_embedded_interior_map);
+    std::vector<unsigned char> file;
+    const char *knob = cb_debug_knob("CUDABROT_AMD_INTERIOR_MAP");
+    if (knob) {  // (a test knob: another map)
+      FILE *f = fopen(knob, "rb");
+      if (f) {
+        unsigned char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + got);
+        fclose(f);
       }
-      fclose(f);
-      if (ok) {
-        unsigned char *d = nullptr;
-        if (hipMalloc(&d, bits.size()) == hipSuccess) {
-          if (hipMemcpy(d, bits.data(), bits.size(), hipMemcpyHostToDevice) == hipSuccess) {
-            g_interior[dev] = InteriorMap{d, header[1], header[2], header[3]};
-          } else {
-            (void) hipFree(d);
-          }
-        }
-      } else {
-        fprintf(stderr, "cudabrot_amd: the interior map file is not one (ignored)\n");
-      }
+      bytes = file.data();
+      n = file.size();
     }
+    DeviceMap m;
+    size_t payload = 0;
+    if (!parse_map(kind, bytes, n, &m, &payload)) {
+      fprintf(stderr, "cudabrot_amd: %s is not a map of the kind it stands for (header, level or length): refused\n",
+              knob ? knob : "the embedded map");
+      return nullptr;
+    }
+    const unsigned char *src = bytes + 16;
+    unsigned char *d = nullptr;
+    if (hipMalloc(&d, payload) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, src, payload, hipMemcpyHostToDevice) != hipSuccess) {
+      (void) hipFree(d);
+      return nullptr;
+    }
+    m.d_bytes = d;
+    g_maps[dev][kind] = m;
+    g_map_state[dev][kind] = 1;
   }
-  return g_interior[dev].d_bits ? &g_interior[dev] : nullptr;
+  return g_map_state[dev][kind] == 1 ? &g_maps[dev][kind] : nullptr;
 }
 
-// The map for a launch of the wave-scheduled kernels (their MID stage in its one-piece form looks samples up; the
-// lock-step kernel and the other forms ignore it): where orbits may be retired early at all -- not the Burning Ship,
-// not the full-iterate variants (CUDABROT_AMD_NO_INTERIOR_MAP=1, a test knob: never).
-void attach_interior_map(cb::DrawArgs &a, bool ship, int base_variant) {
-  g_interior_level = 0;
+// The interior map for a launch of the wave-scheduled kernels (their MID stage in its one-piece form looks samples up;
+// the lock-step kernel and the other forms ignore it): where orbits may be retired early at all -- not the Burning
+// Ship, not the full-iterate variants (CUDABROT_AMD_NO_INTERIOR_MAP=1, a test knob: never).  0, or an error: a map that
+// should be there and is not is never passed over in silence.
+int attach_interior_map(cb::DrawArgs &a, bool ship, int base_variant) {
+  g_interior_level.store(0, std::memory_order_relaxed);
   if (ship || base_variant == CB_KERNEL_FULL_ITERATE || base_variant == CB_KERNEL_SIMPLE ||
       cb_debug_knob("CUDABROT_AMD_TIMED_FULL") != nullptr || cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") != nullptr) {
-    return;
+    return 0;
   }
-  if (const InteriorMap *m = device_interior_map()) {
-    a.interior_map = m->d_bits;
-    a.interior_shift = m->level - 1u;
-    a.interior_cols = m->cols;
-    a.interior_rows = m->rows;
-    g_interior_level = (int) m->level;
-  }
+  const DeviceMap *m = device_map(kMapInterior);
+  if (!m) return (int) hipErrorInvalidValue;
+  a.interior_map = m->d_bytes;
+  a.interior_shift = m->level - 1u;
+  a.interior_cols = m->cols;
+  a.interior_rows = m->rows;
+  g_interior_level.store((int) m->level, std::memory_order_relaxed);
+  return 0;
 }
 
 // x / delta == x * (1 / delta) bit for bit iff delta is a (normal) power of two.
@@ -140,7 +162,7 @@ bool exact_reciprocal(double delta, double *inv) {
 }
 
 // Diagnostic only: which draw kernel the last cb_draw_buddhabrot* call of this process launched (cb_debug_last_draw_kernel).
-int g_last_draw_kernel = 0;
+std::atomic<int> g_last_draw_kernel{0};
 
 // Diagnostic only (CUDABROT_AMD_WAVE_DUMP=<file> with the timed kernel variant): per-wave records of
 // the last launch, see DrawArgs::wave_dump.
@@ -409,8 +431,8 @@ extern "C" {
 
 int cb_abi_version(void) { return CB_ABI_VERSION; }
 
-int cb_debug_last_draw_kernel(void) { return g_last_draw_kernel; }
-int cb_debug_interior_map_level(void) { return g_interior_level; }
+int cb_debug_last_draw_kernel(void) { return g_last_draw_kernel.load(std::memory_order_relaxed); }
+int cb_debug_interior_map_level(void) { return g_interior_level.load(std::memory_order_relaxed); }
 
 const char *cb_error_string(int code) {
   if (code == 0) return "no error";
@@ -474,11 +496,14 @@ int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
     if (rc) return rc;
   }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
+  {
+    const int rc = attach_interior_map(a, ship, base_variant);
+    if (rc) return rc;
+  }
   // the two-waves-per-SIMD kernel where it applies (CUDABROT_AMD_NO_WIDE=1, a test knob: never)
   const bool wide = cb::draw_wide_takes(a) && cb_debug_knob("CUDABROT_AMD_NO_WIDE") == nullptr;
   const auto wide_launch = ship ? cb::launch_draw_wide_ship : cb::launch_draw_wide;
-  g_last_draw_kernel = base_variant == CB_KERNEL_SIMPLE ? 3 : (wide ? 2 : 1);
-  attach_interior_map(a, ship, base_variant);
+  g_last_draw_kernel.store(base_variant == CB_KERNEL_SIMPLE ? 3 : (wide ? 2 : 1), std::memory_order_relaxed);
   switch (base_variant) {
     case CB_KERNEL_DEFAULT:
       return (int) (wide ? wide_launch(a, false, s) : wave(a, false, s));
@@ -544,9 +569,12 @@ int cb_draw_buddhabrot_channels(const cb_fractal_dimensions *dims, cb_pixel *d_h
     int rc = empty_stream_if_nothing_launches(a, reinterpret_cast<hipStream_t>(stream));
     if (rc) return rc;
   }
-  attach_interior_map(a, ship, base_variant);
+  {
+    const int rc = attach_interior_map(a, ship, base_variant);
+    if (rc) return rc;
+  }
   const auto wave = ship ? cb::launch_draw_wave_ship : cb::launch_draw_wave;
-  g_last_draw_kernel = 1;
+  g_last_draw_kernel.store(1, std::memory_order_relaxed);
   return (int) wave(a, false, reinterpret_cast<hipStream_t>(stream));
 }
 

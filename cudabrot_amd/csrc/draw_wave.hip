@@ -1554,6 +1554,8 @@ draw_wave_kernel(DrawArgs a) {
   const uint32_t keep_rest = __builtin_amdgcn_readfirstlane((carry != nullptr && !a.drain) ? 0u : 1u);  // 0: leave in-flight work to the next launch
   const bool has_board = no_board == 0u;
   if (has_board) post_progress_and_set_priority(a.samples_per_thread);
+  // (a record of draw_wide_kernel, tag 2 in both of the headers it lies over: the two kernels do not share carried work)
+  if (carry && carry[0] != 0ull && carry[0] != 1ull) status |= CB_STATUS_CARRY_FOREIGN;
   if (carry && carry[0] == 1ull) {  // wave-uniform: the header is one address
     q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
     q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));

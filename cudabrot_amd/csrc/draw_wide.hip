@@ -92,8 +92,18 @@ constexpr uint32_t kWideQueueWords = sizeof(WideQueues) / 8;
 // carry record of a wave: header, the queues, the lanes' planes (u64 each):
 //   LONG kSlots x {cr, ci, r, i, seen_r, seen_i}, l_rem[0..1], l_rem[2..3], REPLAY {cr, ci, r, i}, {p_start, p_act}
 constexpr uint32_t kWideLanePlanes = kSlots * 6 + 2 + 4 + 1;
-constexpr uint32_t kWideCarryWords = kCarryHeaderWords + kWideQueueWords + kWideLanePlanes * 64;
-static_assert(kWideCarryWords <= 2 * kCarryWordsPerWave, "a wide wave uses the carry records of the two waves it replaces");
+// The record lies over the two records of the waves this one replaces (draw_wave.hip's: kCarryWordsPerWave words each,
+// tag 1 in word 0).  Both headers carry THIS kernel's tag, 2 -- the second record's header words are skipped by the lane
+// planes -- so that either kernel, handed a carry buffer the other one wrote, sees a foreign tag in every record it
+// reads and reports it (CB_STATUS_CARRY_FOREIGN) instead of taking the orbits in it for none.
+constexpr uint32_t kWidePlanesFront = (kCarryWordsPerWave - kCarryHeaderWords - kWideQueueWords) / 64;
+__host__ __device__ constexpr uint32_t wide_plane(uint32_t p) {  // word offset of lane plane p in the record
+  return p < kWidePlanesFront ? kCarryHeaderWords + kWideQueueWords + 64u * p
+                              : kCarryWordsPerWave + kCarryHeaderWords + 64u * (p - kWidePlanesFront);
+}
+static_assert(kCarryHeaderWords + kWideQueueWords <= kCarryWordsPerWave, "the queues end in front of the second header");
+static_assert(wide_plane(kWideLanePlanes - 1) + 64u <= 2 * kCarryWordsPerWave,
+              "a wide wave uses the carry records of the two waves it replaces");
 
 struct Orbit {
   double cr, ci, r, i;
@@ -1399,6 +1409,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   };
   const uint32_t keep_rest = __builtin_amdgcn_readfirstlane(a.drain ? 1u : 0u);  // 0: leave in-flight work to the next launch
   post_progress_and_set_priority(halves_left);
+  if (carry[0] != 0ull && carry[0] != 2ull) status |= CB_STATUS_CARRY_FOREIGN;  // draw_wave_kernel's: not ours to resume
   if (carry[0] == 2ull) {  // wave-uniform: the header is one address (2: a record of this kernel)
     q0_head = (int) __builtin_amdgcn_readfirstlane((uint32_t) carry[1]);
     q0_count = (int) __builtin_amdgcn_readfirstlane((uint32_t) (carry[1] >> 32));
@@ -1410,26 +1421,26 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     unsigned long long *lds_words = reinterpret_cast<unsigned long long *>(&q);
     const unsigned long long *img = carry + kCarryHeaderWords;
     for (uint32_t k = lane_id(); k < kWideQueueWords; k += 64u) lds_words[k] = img[k];
-    const unsigned long long *pl = img + kWideQueueWords + lane_id();
+    const unsigned long long *pl = carry + lane_id();
 #pragma unroll
     for (int o = 0; o < kSlots; ++o) {
-      lo[o].cr = __longlong_as_double((long long) pl[(o * 6 + 0) * 64]);
-      lo[o].ci = __longlong_as_double((long long) pl[(o * 6 + 1) * 64]);
-      lo[o].r = __longlong_as_double((long long) pl[(o * 6 + 2) * 64]);
-      lo[o].i = __longlong_as_double((long long) pl[(o * 6 + 3) * 64]);
-      seen_r[o] = __longlong_as_double((long long) pl[(o * 6 + 4) * 64]);
-      seen_i[o] = __longlong_as_double((long long) pl[(o * 6 + 5) * 64]);
+      lo[o].cr = __longlong_as_double((long long) pl[wide_plane(o * 6 + 0)]);
+      lo[o].ci = __longlong_as_double((long long) pl[wide_plane(o * 6 + 1)]);
+      lo[o].r = __longlong_as_double((long long) pl[wide_plane(o * 6 + 2)]);
+      lo[o].i = __longlong_as_double((long long) pl[wide_plane(o * 6 + 3)]);
+      seen_r[o] = __longlong_as_double((long long) pl[wide_plane(o * 6 + 4)]);
+      seen_i[o] = __longlong_as_double((long long) pl[wide_plane(o * 6 + 5)]);
     }
-    l_rem[0] = (int) (uint32_t) pl[24 * 64];
-    l_rem[1] = (int) (uint32_t) (pl[24 * 64] >> 32);
-    l_rem[2] = (int) (uint32_t) pl[25 * 64];
-    l_rem[3] = (int) (uint32_t) (pl[25 * 64] >> 32);
-    po.cr = __longlong_as_double((long long) pl[26 * 64]);
-    po.ci = __longlong_as_double((long long) pl[27 * 64]);
-    po.r = __longlong_as_double((long long) pl[28 * 64]);
-    po.i = __longlong_as_double((long long) pl[29 * 64]);
-    p_start = (uint32_t) pl[30 * 64];
-    pact = __ballot((pl[30 * 64] >> 32) != 0ull);
+    l_rem[0] = (int) (uint32_t) pl[wide_plane(24)];
+    l_rem[1] = (int) (uint32_t) (pl[wide_plane(24)] >> 32);
+    l_rem[2] = (int) (uint32_t) pl[wide_plane(25)];
+    l_rem[3] = (int) (uint32_t) (pl[wide_plane(25)] >> 32);
+    po.cr = __longlong_as_double((long long) pl[wide_plane(26)]);
+    po.ci = __longlong_as_double((long long) pl[wide_plane(27)]);
+    po.r = __longlong_as_double((long long) pl[wide_plane(28)]);
+    po.i = __longlong_as_double((long long) pl[wide_plane(29)]);
+    p_start = (uint32_t) pl[wide_plane(30)];
+    pact = __ballot((pl[wide_plane(30)] >> 32) != 0ull);
   }
 
   // The launch's first sample: generator A, drawn in logical order, its words then rotated the way the bodies expect
@@ -1718,6 +1729,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     asm volatile("" : "+s"(carry));
     if (lane_id() == 0) {
       carry[0] = 2ull;
+      carry[kCarryWordsPerWave] = 2ull;  // (where draw_wave_kernel's odd waves look for their tag)
       carry[1] = (unsigned long long) (uint32_t) q0_head | ((unsigned long long) (uint32_t) q0_count << 32);
       carry[2] = (unsigned long long) (uint32_t) q1_head | ((unsigned long long) (uint32_t) q1_count << 32);
       carry[3] = (unsigned long long) (uint32_t) q2_head | ((unsigned long long) (uint32_t) q2_count << 32);
@@ -1726,23 +1738,23 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
     const unsigned long long *lds_words = reinterpret_cast<const unsigned long long *>(&q);
     unsigned long long *img = carry + kCarryHeaderWords;
     for (uint32_t k = lane_id(); k < kWideQueueWords; k += 64u) img[k] = lds_words[k];
-    unsigned long long *pl = img + kWideQueueWords + lane_id();
+    unsigned long long *pl = carry + lane_id();
 #pragma unroll
     for (int o = 0; o < kSlots; ++o) {
-      pl[(o * 6 + 0) * 64] = (unsigned long long) __double_as_longlong(lo[o].cr);
-      pl[(o * 6 + 1) * 64] = (unsigned long long) __double_as_longlong(lo[o].ci);
-      pl[(o * 6 + 2) * 64] = (unsigned long long) __double_as_longlong(lo[o].r);
-      pl[(o * 6 + 3) * 64] = (unsigned long long) __double_as_longlong(lo[o].i);
-      pl[(o * 6 + 4) * 64] = (unsigned long long) __double_as_longlong(seen_r[o]);
-      pl[(o * 6 + 5) * 64] = (unsigned long long) __double_as_longlong(seen_i[o]);
+      pl[wide_plane(o * 6 + 0)] = (unsigned long long) __double_as_longlong(lo[o].cr);
+      pl[wide_plane(o * 6 + 1)] = (unsigned long long) __double_as_longlong(lo[o].ci);
+      pl[wide_plane(o * 6 + 2)] = (unsigned long long) __double_as_longlong(lo[o].r);
+      pl[wide_plane(o * 6 + 3)] = (unsigned long long) __double_as_longlong(lo[o].i);
+      pl[wide_plane(o * 6 + 4)] = (unsigned long long) __double_as_longlong(seen_r[o]);
+      pl[wide_plane(o * 6 + 5)] = (unsigned long long) __double_as_longlong(seen_i[o]);
     }
-    pl[24 * 64] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
-    pl[25 * 64] = (unsigned long long) (uint32_t) l_rem[2] | ((unsigned long long) (uint32_t) l_rem[3] << 32);
-    pl[26 * 64] = (unsigned long long) __double_as_longlong(po.cr);
-    pl[27 * 64] = (unsigned long long) __double_as_longlong(po.ci);
-    pl[28 * 64] = (unsigned long long) __double_as_longlong(po.r);
-    pl[29 * 64] = (unsigned long long) __double_as_longlong(po.i);
-    pl[30 * 64] = (unsigned long long) p_start | ((unsigned long long) (lane_in(pact) ? 1u : 0u) << 32);
+    pl[wide_plane(24)] = (unsigned long long) (uint32_t) l_rem[0] | ((unsigned long long) (uint32_t) l_rem[1] << 32);
+    pl[wide_plane(25)] = (unsigned long long) (uint32_t) l_rem[2] | ((unsigned long long) (uint32_t) l_rem[3] << 32);
+    pl[wide_plane(26)] = (unsigned long long) __double_as_longlong(po.cr);
+    pl[wide_plane(27)] = (unsigned long long) __double_as_longlong(po.ci);
+    pl[wide_plane(28)] = (unsigned long long) __double_as_longlong(po.r);
+    pl[wide_plane(29)] = (unsigned long long) __double_as_longlong(po.i);
+    pl[wide_plane(30)] = (unsigned long long) p_start | ((unsigned long long) (lane_in(pact) ? 1u : 0u) << 32);
   }
   const unsigned long long skipped_total = wave_sum(((unsigned long long) skip_hi << 32) | skip_lo) + skipped_s;
   const unsigned long long counted_total = wave_sum((unsigned long long) counted) + counted_s;

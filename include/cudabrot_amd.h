@@ -66,7 +66,8 @@ typedef struct {
   uint64_t replay_steps;   /* iterations of IterateAndRecord (cudabrot.cu:352)           */
   uint64_t increments;     /* histogram increments (cudabrot.cu:312)                     */
   uint64_t skipped_steps;  /* part of iterate_steps NOT executed: the orbit was found to be
-                              exactly periodic, so it can never escape                   */
+                              exactly periodic, or its cell is proven never-escaping (the
+                              interior map)                                               */
   uint64_t status;         /* 0 = ok; nonzero = internal invariant violated (CB_STATUS_*) */
   /* CB_KERNEL_TIMED only (else 0): shader-clock cycles summed over waves, per stage and in total */
   uint64_t cycles_head, cycles_long, cycles_replay, cycles_total;
@@ -78,6 +79,8 @@ typedef struct {
 #define CB_STATUS_QUEUE_OVERFLOW 1u
 #define CB_STATUS_REPLAY_RUNAWAY 2u
 #define CB_STATUS_INTERIOR_MAP 4u /* a sample of a cell proven never-escaping (interior map) escaped */
+#define CB_STATUS_CARRY_FOREIGN 8u /* the carry buffer holds work of the OTHER draw kernel (another workspace size or
+                                      none picks another kernel: see cb_draw_buddhabrot): it was not resumed */
 /* Returned (instead of a hipError_t) by cb_renderer_finish and by everything that reads a renderer's histogram
  * or image when cb_counters.status is nonzero: a draw kernel saw one of its internal invariants broken and has
  * lost samples, so the histogram is not a result.  cb_renderer_read_counters still succeeds and shows the flags. */
@@ -143,8 +146,11 @@ size_t cb_scatter_workspace_bytes_channels(const cb_fractal_dimensions *dims, in
  * hundreds of iterations with almost every lane idle, so with a carry buffer the launch stops when
  * its samples are drawn.  A final call with samples_per_thread == 0 (followed by its
  * cb_flush_scatter) completes the carried work; only then do d_hist and d_counters account for
- * every sample drawn.  Same geometry, iteration control and kernel variant for all calls sharing a
- * carry buffer. */
+ * every sample drawn.  Same geometry, iteration control, kernel variant AND workspace (its size, or none)
+ * for all calls sharing a carry buffer: the library has two draw kernels with carry records of their own and
+ * picks one by the shape of the launch, the workspace included.  A call that finds the other kernel's work
+ * in the buffer does not resume it and says so: cb_counters.status gets CB_STATUS_CARRY_FOREIGN (cb_renderer
+ * keeps all of this consistent by itself). */
 int cb_draw_buddhabrot(const cb_fractal_dimensions *dims, cb_pixel *d_hist,
                        const cb_iteration_control *iterations, void *d_states, uint32_t n_threads,
                        uint32_t samples_per_thread, cb_counters *d_counters, int kernel_variant,
@@ -285,8 +291,8 @@ const char *cb_debug_knob(const char *name);
  * scatter), 3 the lock-step baseline.  The kernels give identical results; tests use this to know what they covered. */
 int cb_debug_last_draw_kernel(void);
 /* The level of the interior map the last cb_draw_buddhabrot call of this process used (cells of side 2^-level of the
- * c-plane whose samples provably never escape: the draw kernel retires them without iterating; built by `make` as
- * interior_map.bin beside the library, see tools/interior_map.c), 0 if it used none.  Results do not depend on it. */
+ * c-plane whose samples provably never escape: the draw kernel retires them without iterating; made and proven by
+ * tools/interior_map.c, embedded in the library), 0 if it used none.  Results do not depend on it. */
 int cb_debug_interior_map_level(void);
 
 #ifdef __cplusplus

@@ -14,12 +14,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 def built_level():
-    """The level of the map `make` put beside the library (its header)."""
+    """The level of the map kept in the tree (its header), which `make` embeds in the library."""
+    import gzip
     import os
     import struct
 
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudabrot_amd", "interior_map.bin")
-    magic, level, _, _ = struct.unpack("<4I", open(path, "rb").read(16))
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cudabrot_amd", "interior_map.bin.gz")
+    magic, level, _, _ = struct.unpack("<4I", gzip.open(path, "rb").read(16))
     assert magic == 0x4D494243
     return level
 
@@ -46,11 +47,11 @@ def same(a, b):
 
 
 def test_the_map_is_built_loaded_and_used(cb, oracle, monkeypatch):
-    """`make` builds interior_map.bin beside the library (level 12, proven nine levels of quarters deep); the wide kernel uses it and skips more iterations
+    """`make` embeds the kept map in the library (level 12, proven nine levels of quarters deep); the wide kernel uses it and skips more iterations
     than the periodicity check alone -- with the oracle's histogram and counters."""
     args = (512, 512, 2000, 8192, 8)
     with_map = render(cb, *args)
-    assert with_map[2] == WIDE and with_map[3] == built_level() >= 10, "no interior map in use (cudabrot_amd/interior_map.bin: run make)"
+    assert with_map[2] == WIDE and with_map[3] == built_level() >= 10, "no interior map in use"
     monkeypatch.setenv("CUDABROT_AMD_NO_INTERIOR_MAP", "1")
     without = render(cb, *args)
     assert without[2] == WIDE and without[3] == 0
@@ -62,43 +63,60 @@ def test_the_map_is_built_loaded_and_used(cb, oracle, monkeypatch):
         assert with_map[1][k] == ref[1][k], (k, with_map[1][k], ref[1][k])
 
 
-def test_without_the_file_or_with_a_wrong_one_nothing_changes_but_the_work(cb, tmp_path, monkeypatch):
-    """The library finds the map beside itself; a missing file, or one that is not a map, leaves the draw kernel as it
-    was before there was one (CUDABROT_AMD_INTERIOR_MAP: a test knob naming another file; read once per device and
-    process, hence the subprocesses)."""
+def test_the_map_is_embedded_and_another_one_must_be_one_to_the_byte(cb, tmp_path):
+    """VERDICT r03 #2a / ADVICE r03: the map decides results, so there is no file to find, lose or swap -- the library
+    carries it (maps.S; `make` has checked its sha256 against the digest in the tree).  The one way to hand it another
+    (CUDABROT_AMD_INTERIOR_MAP behind CUDABROT_AMD_DEBUG=1, a test knob; read once per device and process, hence the
+    subprocesses) takes a map of exactly the right header AND length, and anything else -- no such file, not a map, a
+    map one byte too long -- is an ERROR of the draw call, never a silent run without or with half a map.  Without any
+    map (CUDABROT_AMD_NO_INTERIOR_MAP=1) the results are the same and more iterations are made."""
+    import gzip
     import json
+    import os
     import subprocess
     import sys
 
     prog = (
         "import json, numpy as np, cudabrot_amd as cb\n"
         "dims = cb.FractalDimensions.make(256, 256)\n"
-        "with cb.Renderer(dims, cb.IterationControl(1000, 20), n_threads=4096) as r:\n"
-        "    r.render_passes(4)\n"
-        "    h = r.read_histogram(); c = r.read_counters().as_dict()\n"
+        "try:\n"
+        "    with cb.Renderer(dims, cb.IterationControl(1000, 20), n_threads=4096) as r:\n"
+        "        r.render_passes(4)\n"
+        "        h = r.read_histogram(); c = r.read_counters().as_dict()\n"
+        "except cb.CudabrotError as e:\n"
+        "    print(json.dumps({'error': e.code})); raise SystemExit(0)\n"
         "print(json.dumps({'level': cb.lib.cb_debug_interior_map_level(), 'sum': int(h.sum()), 'crc': int(np.bitwise_xor.reduce(h.ravel() * np.arange(1, h.size + 1, dtype=np.uint64))),"
         " 'never': c['never_escaped'], 'skipped': c['skipped_steps'], 'iterate': c['iterate_steps'], 'status': c['status']}))\n"
     )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    raw = gzip.open(os.path.join(root, "cudabrot_amd", "interior_map.bin.gz"), "rb").read()
+    good = tmp_path / "copy_of_the_kept_map.bin"
+    good.write_bytes(raw)
     bad = tmp_path / "not_a_map.bin"
     bad.write_bytes(b"CBIM" + bytes(100))
+    long_ = tmp_path / "one_byte_too_long.bin"
+    long_.write_bytes(raw + b"\0")
+    short = tmp_path / "truncated.bin"
+    short.write_bytes(raw[: len(raw) // 2])
 
-    def run(path):
-        env = dict(__import__("os").environ, CUDABROT_AMD_DEBUG="1")
-        if path is not None:
-            env["CUDABROT_AMD_INTERIOR_MAP"] = str(path)
+    def run(**knobs):
+        env = dict(os.environ, CUDABROT_AMD_DEBUG="1", **{k: str(v) for k, v in knobs.items()})
         out = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, check=True)
         return json.loads(out.stdout.strip().splitlines()[-1]), out.stderr
 
-    with_map, _ = run(None)
-    missing, _ = run(tmp_path / "no_such_file.bin")
-    wrong, err = run(bad)
-    assert with_map["level"] == built_level() and missing["level"] == 0 and wrong["level"] == 0
-    assert "interior map" in err
-    for other in (missing, wrong):
-        assert other["status"] == 0
-        for k in ("sum", "crc", "never", "iterate"):
-            assert other[k] == with_map[k], k
-        assert other["skipped"] < with_map["skipped"]
+    with_map, _ = run()
+    assert with_map["level"] == built_level() and with_map["status"] == 0
+    other, _ = run(CUDABROT_AMD_INTERIOR_MAP=good)
+    assert other == with_map
+    for path in (tmp_path / "no_such_file.bin", bad, long_, short):
+        refused, err = run(CUDABROT_AMD_INTERIOR_MAP=path)
+        assert "error" in refused and refused["error"] != 0, (path, refused)
+        assert "refused" in err, err
+    without, _ = run(CUDABROT_AMD_NO_INTERIOR_MAP=1)
+    assert without["level"] == 0 and without["status"] == 0
+    for k in ("sum", "crc", "never", "iterate"):
+        assert without[k] == with_map[k], k
+    assert without["skipped"] < with_map["skipped"]
 
 
 def test_ten_billion_samples_against_full_iteration(cb):
@@ -135,3 +153,61 @@ def test_windows_made_of_interior(cb, box):
     assert product[2] == WIDE and product[3] == built_level()
     full = render(cb, *args, box=box, variant=cb.CB_KERNEL_FULL_ITERATE)
     same(product, full)
+
+
+def marked_cells_and_depths():
+    """The marked cells of the kept map (their indices) and, if the tree has them, the depth each proof needed
+    (cudabrot_amd/interior_map.depths.gz: `make verify-interior-map`)."""
+    import gzip
+    import os
+    import struct
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    raw = gzip.open(os.path.join(root, "cudabrot_amd", "interior_map.bin.gz"), "rb").read()
+    magic, level, cols, rows = struct.unpack("<4I", raw[:16])
+    marked = np.flatnonzero(np.unpackbits(np.frombuffer(raw, dtype=np.uint8, offset=16), bitorder="little"))
+    depths = None
+    side = os.path.join(root, "cudabrot_amd", "interior_map.depths.gz")
+    if os.path.exists(side):
+        d = gzip.open(side, "rb").read()
+        m2, l2, n2, _ = struct.unpack("<4I", d[:16])
+        assert m2 == 0x44494243 and l2 == level and n2 == marked.size
+        depths = np.frombuffer(d, dtype=np.uint8, offset=16)
+    return level, cols, rows, marked, depths
+
+
+def test_the_reference_s_own_function_never_escapes_inside_marked_cells(cb, oracle):
+    """VERDICT r03 #2d: the map's claim, put to the reference's OWN IterateMandelbrot (cudabrot.cu:319-340, compiled for
+    gfx950 with its own flags: oracle/_ref/libref_probe.so) on the MI355X -- 10^8 points drawn inside marked cells, half
+    of them inside the cells whose proof went deepest (the boundary layer, where a wrong bit would be), at max_iter 20000
+    and 60000: every one must come back as max_iter (never escaped), which is what the kernel books for a marked sample
+    without iterating it (cudabrot.cu:407)."""
+    import ctypes as C
+    import os
+
+    path = os.path.join(oracle.REF_DIR, "libref_probe.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/libref_probe.so not built (make -C oracle ref, needs /root/reference)")
+    probe = C.CDLL(path)
+    probe.ref_probe_points.restype = C.c_int
+    probe.ref_probe_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    level, cols, rows, marked, depths = marked_cells_and_depths()
+    deep = marked if depths is None else marked[depths >= max(1, int(np.percentile(depths, 90)))]
+    s = 2.0 ** -level
+    rng = np.random.default_rng(2026)
+    batch, total = 5_000_000, 0
+    for max_iter, batches in ((20000, 16), (60000, 4)):
+        for _ in range(batches):
+            cells = np.concatenate([rng.choice(marked, batch // 2), rng.choice(deep, batch - batch // 2)])
+            re = -2.0 + (cells % cols + rng.random(batch)) * s
+            im = (cells // cols + rng.random(batch)) * s * rng.choice(np.array([-1.0, 1.0]), batch)
+            re, im = np.ascontiguousarray(re), np.ascontiguousarray(im)
+            k = np.empty(batch, dtype=np.int32)
+            sc = np.empty(batch, dtype=np.int32)
+            rc = probe.ref_probe_points(re.ctypes.data, im.ctypes.data, batch, max_iter, k.ctypes.data, sc.ctypes.data)
+            assert rc == 0, "HIP error %d in the probe" % rc
+            bad = np.flatnonzero(k != max_iter)
+            assert bad.size == 0, "the reference escapes at %s inside a marked cell: c = %r %r" % (
+                k[bad[:3]], re[bad[:3]], im[bad[:3]])
+            total += batch
+    assert total >= 100_000_000

@@ -192,3 +192,41 @@ def test_launches_the_wide_kernel_does_not_take(cb, monkeypatch):
     assert render(cb, 256, 256, 500, 100, 4096, 2)[2] == WAVE         # min_iter beyond the LONG stage's start
     monkeypatch.setenv("CUDABROT_AMD_NO_WORKSPACE", "1")
     assert render(cb, 256, 256, 500, 20, 4096, 2)[2] == WAVE
+
+
+@pytest.mark.parametrize("first_wide", [True, False], ids=["wide_then_wave", "wave_then_wide"])
+def test_a_carry_buffer_of_the_other_kernel_is_reported_not_resumed(cb, first_wide):
+    """the two draw kernels keep carry records of their own and the library picks the kernel by the launch's
+    shape (workspace included).  A low-level caller who changes the workspace between calls that share a carry buffer
+    switches kernel: the second one must SAY that it found the other one's work (CB_STATUS_CARRY_FOREIGN), in every
+    wave -- not drop the orbits in silence."""
+    import torch
+
+    w, h, threads = 512, 512, 4096
+    dims = cb.FractalDimensions.make(w, h)
+    it = cb.IterationControl(2000, 20)
+    dev = torch.device("cuda", 0)
+    hist = torch.zeros(w * h, dtype=torch.int64, device=dev)
+    states = torch.empty(cb.rng_state_bytes(threads), dtype=torch.uint8, device=dev)
+    counters = torch.zeros(17, dtype=torch.int64, device=dev)
+    size = cb.scatter_workspace_bytes(dims, threads, 50 * 8)
+    ws = torch.empty(size, dtype=torch.uint8, device=dev)
+    carry = torch.zeros(cb.carry_bytes(threads), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    cb.initialize_rng(cb.CB_DEFAULT_RNG_SEED, 0, threads, states.data_ptr(), stream)
+
+    def launch(with_workspace, samples):
+        cb.draw_buddhabrot(dims, hist.data_ptr(), it, states.data_ptr(), threads, samples, counters.data_ptr(),
+                           cb.CB_KERNEL_DEFAULT, stream, ws.data_ptr() if with_workspace else 0,
+                           size if with_workspace else 0, carry.data_ptr())
+        kernel = cb.lib.cb_debug_last_draw_kernel()
+        if with_workspace:
+            cb.flush_scatter(dims, hist.data_ptr(), threads, ws.data_ptr(), size, stream)
+        torch.cuda.synchronize()
+        return kernel, int(counters.cpu().numpy().view(np.uint64)[9])
+
+    kernel, status = launch(first_wide, 50 * 8)          # leaves orbits in flight in the carry buffer
+    assert kernel == (WIDE if first_wide else WAVE) and status == 0
+    kernel, status = launch(not first_wide, 0)           # the drain, with the other kernel
+    assert kernel == (WAVE if first_wide else WIDE)
+    assert status & cb.CB_STATUS_CARRY_FOREIGN, "the other kernel's carried orbits were dropped without a word"

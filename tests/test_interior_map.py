@@ -91,6 +91,25 @@ def test_the_kept_map_against_the_prover(tool, tmp_path):
     assert worst < 1.99, worst
     out = run(tool, "check", "12", kept, "400000")
     assert re.search(r"400000 samples inside %d marked cells iterated to 20000: 0 escaped" % n_kept, out), out
-    built = os.path.join(ROOT, "cudabrot_amd", "interior_map.bin")
-    if os.path.exists(built):                             # what `make` unpacked beside the library
+    built = os.path.join(ROOT, "cudabrot_amd", "csrc", "build", "interior_map.bin")
+    if os.path.exists(built):                             # what `make` unpacked (and embeds in the library)
         assert open(built, "rb").read() == raw
+
+
+def test_the_kept_map_is_the_pinned_one_and_the_embedded_one():
+    """The map that decides results is pinned three ways: the digest kept in the tree (csrc/map_digests.sha256, which
+    `make` checks before it assembles the map into the library), the kept file, and the bytes the built library carries."""
+    import ctypes
+    import hashlib
+
+    raw = gzip.open(KEPT, "rb").read()
+    pinned = open(os.path.join(ROOT, "cudabrot_amd", "csrc", "map_digests.sha256")).read().split()
+    assert pinned[1].endswith("interior_map.bin") and hashlib.sha256(raw).hexdigest() == pinned[0]
+    lib = os.path.join(ROOT, "cudabrot_amd", "libcudabrot_amd.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    so = ctypes.CDLL(lib)
+    begin = ctypes.addressof(ctypes.c_ubyte.in_dll(so, "cb_embedded_interior_map"))
+    end = ctypes.addressof(ctypes.c_ubyte.in_dll(so, "cb_embedded_interior_map_end"))
+    assert end - begin == len(raw)
+    assert ctypes.string_at(begin, end - begin) == raw

@@ -34,6 +34,9 @@
 //                                            periodicity check alone and with the map in front of it
 //   ./interior_map check LEVEL map.bin N     N samples drawn INSIDE marked cells, iterated to max_iter 20000 with the
 //                                            reference's arithmetic: how many escape (must be 0)
+//   ./interior_map verify LEVEL map.bin D depths.bin [SAMPLE SKIP_BELOW SEED]
+//                                            re-prove the marked cells of a kept map (all of them, noting the depth each
+//                                            proof needed in depths.bin; or a stratified sample against those notes)
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -131,6 +134,24 @@ static int verify_square(double c0r, double c0i, double h, int depth) {
   return 1;
 }
 
+// verify_square, also reporting how many levels of quarters the proof went down (the smallest `depth` it succeeds with:
+// the recursion subdivides only where the one-disc proof fails, so a larger budget never changes the tree above).
+static int verify_square_depth(double c0r, double c0i, double h, int depth, int *used) {
+  const bound_t rc = ((bound_t) h + 0x1p-40) * 1.4142135623730951 * kInflate;
+  const int proven = verify_cell(c0r, c0i, rc, 20000);
+  *used = 0;
+  if (proven != 0 || depth == 0) return proven;
+  const double q = 0.5 * h;
+  int deepest = 0;
+  for (int k = 0; k < 4; ++k) {
+    int u = 0;
+    if (verify_square_depth(c0r + ((k & 1) ? q : -q), c0i + ((k & 2) ? q : -q), q, depth - 1, &u) != 1) return 0;
+    if (u > deepest) deepest = u;
+  }
+  *used = deepest + 1;
+  return 1;
+}
+
 static long cols_of(int level) { return (long) ldexp(RE_SPAN, level); }
 static long rows_of(int level) { return (long) ldexp(IM_SPAN, level); }
 static inline long cell_of(double cr, double ci, int level, long cols, long rows) {  // -1: outside the map
@@ -152,7 +173,7 @@ static int sched(unsigned c) {  // the kernel's schedule of saved points: chunk 
 static inline uint64_t bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 
 int main(int argc, char **argv) {
-  if (argc < 4) { fprintf(stderr, "usage: interior_map make|model|check LEVEL file [N]\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: interior_map make|model|check|verify LEVEL file [N]\n"); return 2; }
   const int level = atoi(argv[2]);
   const long cols = cols_of(level), rows = rows_of(level), cells = cols * rows;
   const size_t bytes = (size_t) (cells + 7) / 8;
@@ -189,6 +210,86 @@ int main(int argc, char **argv) {
   if (!f || fread(header, 1, 16, f) != 16 || header[0] != 0x4d494243u || header[1] != (uint32_t) level ||
       fread(map, 1, bytes, f) != bytes) { fprintf(stderr, "%s: not a level-%d map\n", argv[3], level); return 1; }
   fclose(f);
+  if (!strcmp(argv[1], "verify")) {
+    // Re-prove the marked cells of a kept map, each with up to DEPTH levels of quarters, and note the depth every proof
+    // needed in a sidecar: "CBID", LEVEL, marked cells, DEPTH (u32 each), then one byte per marked cell in the order of
+    // their indices (0xff: not proven yet).  A sidecar that exists is continued (cells with a depth are skipped unless
+    // SAMPLE is given); SAMPLE > 0: re-prove only the cells whose noted depth exceeds SKIP_BELOW plus SAMPLE others drawn
+    // with SEED (the stratified check of tests/test_interior_map.py), changing nothing in the file.
+    //   ./interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED]
+    if (argc < 6) { fprintf(stderr, "usage: interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED]\n"); return 2; }
+    const int depth = atoi(argv[4]);
+    const long sample = argc > 6 ? atol(argv[6]) : 0;
+    const int skip_below = argc > 7 ? atoi(argv[7]) : 3;
+    if (argc > 8) rng_state ^= (uint64_t) atol(argv[8]) * 0x9e3779b97f4a7c15ull;
+    const double s = ldexp(1.0, -level);
+    long *marked = malloc(sizeof(long) * ((size_t) cells / 8 + 64));
+    long nm = 0;
+    for (long k = 0; k < cells; ++k) if ((map[k >> 3] >> (k & 7)) & 1) marked[nm++] = k;
+    uint8_t *used = malloc((size_t) nm + 1);
+    memset(used, 0xff, (size_t) nm + 1);
+    FILE *g = fopen(argv[5], "rb");
+    if (g) {
+      uint32_t h4[4];
+      if (fread(h4, 1, 16, g) != 16 || h4[0] != 0x44494243u || h4[1] != (uint32_t) level || h4[2] != (uint32_t) nm ||
+          fread(used, 1, (size_t) nm, g) != (size_t) nm) { fprintf(stderr, "%s: not the depths of this map\n", argv[5]); return 1; }
+      fclose(g);
+    } else if (sample > 0) { fprintf(stderr, "%s: missing (a sample needs the noted depths)\n", argv[5]); return 1; }
+    uint8_t *todo = calloc((size_t) nm + 1, 1);
+    long n_todo = 0;
+    if (sample > 0) {
+      for (long k = 0; k < nm; ++k) if (used[k] == 0xff || used[k] > skip_below) { todo[k] = 1; ++n_todo; }
+      for (long k = 0; k < sample; ++k) {
+        const long j = (long) (uniform01() * (double) nm);
+        if (j < nm && !todo[j]) { todo[j] = 1; ++n_todo; }
+      }
+    } else {
+      for (long k = 0; k < nm; ++k) if (used[k] == 0xff) { todo[k] = 1; ++n_todo; }
+    }
+    printf("%ld marked cells, %ld to prove at depth <= %d\n", nm, n_todo, depth);
+    fflush(stdout);
+    long failed = 0, done = 0, mismatched = 0;
+    const uint32_t h4[4] = {0x44494243u /* "CBID" */, (uint32_t) level, (uint32_t) nm, (uint32_t) depth};
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : failed, mismatched)
+    for (long k = 0; k < nm; ++k) {
+      if (!todo[k]) continue;
+      const long cell = marked[k], x = cell % cols, y = cell / cols;
+      const double c0r = RE_MIN + (x + 0.5) * s, c0i = (y + 0.5) * s;
+      int u = 0;
+      const int ok = verify_square_depth(c0r, c0i, 0.5 * s, depth, &u) == 1;
+      if (!ok) {
+        if (++failed <= 20) printf("NOT PROVEN at depth %d: cell %ld (column %ld, row %ld)\n", depth, cell, x, y);
+      } else if (sample > 0) {
+        if (used[k] != 0xff && used[k] != (uint8_t) u) ++mismatched;
+      } else {
+        used[k] = (uint8_t) u;
+      }
+      long d;
+#pragma omp atomic capture
+      d = ++done;
+      if (sample == 0 && d % 20000 == 0) {
+#pragma omp critical
+        {
+          FILE *o = fopen(argv[5], "wb");  // (a cell being written right now is 0xff or its depth: either is true)
+          if (o) { fwrite(h4, 1, 16, o); fwrite(used, 1, (size_t) nm, o); fclose(o); }
+          printf("%ld of %ld\n", d, n_todo);
+          fflush(stdout);
+        }
+      }
+    }
+    if (sample == 0) {
+      FILE *o = fopen(argv[5], "wb");
+      if (!o || fwrite(h4, 1, 16, o) != 16 || fwrite(used, 1, (size_t) nm, o) != (size_t) nm) { perror(argv[5]); return 1; }
+      fclose(o);
+    }
+    long by_depth[17] = {0};
+    for (long k = 0; k < nm; ++k) by_depth[used[k] == 0xff ? 16 : (used[k] > 15 ? 15 : used[k])]++;
+    printf("proved %ld cells, %ld NOT proven, %ld with another depth than noted; cells by depth:", done - failed, failed, mismatched);
+    for (int d = 0; d < 16; ++d) if (by_depth[d]) printf(" %d:%ld", d, by_depth[d]);
+    if (by_depth[16]) printf(" unknown:%ld", by_depth[16]);
+    printf("\n");
+    return failed != 0 || mismatched != 0;
+  }
   const long n = argc > 4 ? atol(argv[4]) : 1000000;
   const int max_iter = 20000, start = 20, chunk = 60;
   if (!strcmp(argv[1], "model")) {
