@@ -293,24 +293,23 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
   "v_fma_f64 %[cr], %[nr], %[k2m50], %[kk]\n\t"                            \
   "v_fma_f64 %[ci], %[ni], %[k2m50], %[kk]\n\t"
 
-// Behind a body: the ring, and whether the next body runs.  The statement ends behind the body after which  the
-// input has ended (halves == 0: the pending sample is the launch's last, the caller tests it),  or Q0 holds a MID
-// pass (q0_count >= 64),  or the progress board is due (halves % 256 == 0) -- one test and one branch for the three;
-// the state (hs) is set on the way out only (the stubs CBW_EXIT).  rejected / escaped-in-HEAD are made from acc0 and
-// the growth of q0_count behind the loop.
+// Behind a body: the ring, and whether the next body runs.  The statement ends behind the body after which Q0 holds a
+// MID pass (nroom = q0_count - 64 has carried) or the caller's count of bodies is used up (ctr: the input has ended --
+// the pending sample is then the launch's last, the caller tests it -- or the progress board is due): a scalar
+// instruction and a branch not taken each (round 4: six scalar instructions instead of ten); the state (hs) is set on
+// the way out only (the stubs CBW_EXIT).  rejected / escaped-in-HEAD are made from acc0 and the growth of q0_count
+// behind the loop.
 #define CBW_AFTER(exit_label, next_label)                            \
   "s_bcnt1_i32_b64 %[tmp], %[m1]\n\t"                                \
-  "s_sub_u32 %[halves], %[halves], 1\n\t"                            \
-  "s_add_u32 %[q0c], %[q0c], %[tmp]\n\t"                             \
   "s_add_u32 %[tail], %[tail], %[tmp]\n\t"                           \
-  "s_and_b32 %[tmp], %[halves], 255\n\t"     /* 0: the board is due */ \
-  "s_min_u32 %[tmp], %[tmp], %[halves]\n\t"  /* 0: the input has ended */ \
-  "s_cmp_lt_u32 %[q0c], 64\n\t"                                      \
-  "s_cselect_b32 %[tmp], %[tmp], 0\n\t"      /* 0: Q0 holds a MID pass */ \
-  "s_cmp_eq_u32 %[tmp], 0\n\t"                                       \
+  "s_add_u32 %[nroom], %[nroom], %[tmp]\n\t"                         \
+  "s_cbranch_scc1 7" exit_label "f\n\t"                              \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                                  \
   "s_cbranch_scc1 " exit_label "f\n\t"                               \
   next_label
 #define CBW_EXIT(label, next_hs)                                     \
+  "7" label ":\n\t"                                                  \
+  "s_sub_u32 %[ctr], %[ctr], 1\n\t"                                  \
   label ":\n\t"                                                      \
   "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
   "s_branch 99f\n\t"
@@ -345,7 +344,11 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
   n_rejected = __builtin_amdgcn_readfirstlane(n_rejected);
   n_too_fast = __builtin_amdgcn_readfirstlane(n_too_fast);
   n_steps = __builtin_amdgcn_readfirstlane(n_steps);
-  const uint32_t halves_before = halves, q0_before = q0_count;
+  // bodies until the input ends or the board is due (halves % 256 == 0), counted down from one less
+  static_assert(kPrioHalves == 256, "a call ends where halves % 256 == 0");
+  const uint32_t n_bodies = ((halves - 1u) & (kPrioHalves - 1u)) + 1u;
+  uint32_t ctr = n_bodies - 1u, nroom = q0_count - 64u;
+  const uint32_t q0_before = q0_count;
   asm volatile(
       "s_mov_b64 %[save], exec\n\t"
       "s_cmp_eq_u32 %[en], 0\n\t"
@@ -390,7 +393,7 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
       "99:\n\t"
       "s_mov_b64 exec, %[save]\n\t"
       "s_nop 4\n\t"
-      : [halves] "+s"(halves), [hs] "+s"(hs), [tail] "+s"(q0_tail), [q0c] "+s"(q0_count), [acc0] "+s"(acc0),
+      : [ctr] "+s"(ctr), [hs] "+s"(hs), [tail] "+s"(q0_tail), [nroom] "+s"(nroom), [acc0] "+s"(acc0),
         [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
         [save] "=&s"(save), [tmp] "=&s"(tmp), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
         [q] "=&v"(q), [slot] "=&v"(slot), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
@@ -401,7 +404,11 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
         [k3] "s"(3u * 362437u), [k4] "s"(4u * 362437u)
       : "vcc", "scc", "memory");
   // rejected: the lanes inside a region; escaped in HEAD (too fast): outside both regions and not among the survivors
-  const uint32_t bodies = halves_before - halves, survivors = q0_count - q0_before;
+  // (ctr has gone down by one per body that ran, past zero if all of them did)
+  const uint32_t bodies = enable ? n_bodies - 1u - __builtin_amdgcn_readfirstlane(ctr) : 0u;
+  halves -= bodies;
+  q0_count = __builtin_amdgcn_readfirstlane(nroom) + 64u;
+  const uint32_t survivors = q0_count - q0_before;
   n_rejected += 64u * bodies - acc0;
   n_too_fast += acc0 - survivors;
 }

@@ -4,7 +4,7 @@
 set -u
 name=$1; rounds=${2:-2}
 mkdir -p gpurun_out
-cp cudabrot_amd/libcudabrot_amd.so gpurun_out/lib_mine.so; cp cudabrot_amd/capi.py gpurun_out/capi_mine.py
+cp cudabrot_amd/libcudabrot_amd.so gpurun_out/lib_mine.so; cp cudabrot_amd/capi.py gpurun_out/capi_mine.py; cp cudabrot_amd/__init__.py gpurun_out/init_mine.py
 line() { python3 - "$1" "$2" <<'PY'
 import json, sys
 tag, path = sys.argv[1], sys.argv[2]
@@ -18,10 +18,10 @@ PY
 }
 for k in $(seq $rounds); do
   for v in $name mine; do
-    if [ $v = mine ]; then cp gpurun_out/lib_mine.so cudabrot_amd/libcudabrot_amd.so; cp gpurun_out/capi_mine.py cudabrot_amd/capi.py; rm -f cudabrot_amd/interior_map.bin
+    if [ $v = mine ]; then cp gpurun_out/lib_mine.so cudabrot_amd/libcudabrot_amd.so; cp gpurun_out/capi_mine.py cudabrot_amd/capi.py; cp gpurun_out/init_mine.py cudabrot_amd/__init__.py; rm -f cudabrot_amd/interior_map.bin
     else cp tools/_ab/$v/* cudabrot_amd/; fi
     timeout -k 10 150 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs > gpurun_out/ab_$v.log 2>&1
     line $v gpurun_out/ab_$v.log
   done
 done
-cp gpurun_out/lib_mine.so cudabrot_amd/libcudabrot_amd.so; cp gpurun_out/capi_mine.py cudabrot_amd/capi.py; rm -f gpurun_out/lib_mine.so gpurun_out/capi_mine.py cudabrot_amd/interior_map.bin
+cp gpurun_out/lib_mine.so cudabrot_amd/libcudabrot_amd.so; cp gpurun_out/capi_mine.py cudabrot_amd/capi.py; cp gpurun_out/init_mine.py cudabrot_amd/__init__.py; rm -f gpurun_out/lib_mine.so gpurun_out/capi_mine.py gpurun_out/init_mine.py cudabrot_amd/interior_map.bin
