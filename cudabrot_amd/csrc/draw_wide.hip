@@ -314,6 +314,25 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
   "s_mov_b32 %[hs], " next_hs "\n\t"                                 \
   "s_branch 99f\n\t"
 
+// On the way in: the PENDING sample -- the one the body before drew, whose test this call's first body makes -- is not
+// kept in registers across the other stages (round 4: four persistent registers fewer): a generator's words x1..x4 ARE
+// the xorshift words of its last four outputs, so until it draws again
+//   out_j = d + x_j - (4 - j) * 362437        (rocrand_xorwow.h:174-176: out = d_j + x_new, d_j = d - (4 - j) * 362437)
+// and the coordinates are made from them again (sample_coordinate2): 14 vector instructions per call of the statement.
+// X1..X4, XD: the logical words and the Weyl value of the generator that drew it, as they are NOW (the mapping of the
+// body that draws from it next).
+#define CBW_PENDING(X1, X2, X3, X4, XD)                              \
+  "v_add3_u32 %[o1], " XD ", " X1 ", %[km3]\n\t"                     \
+  "v_add3_u32 %[o2], " XD ", " X2 ", %[km2]\n\t"                     \
+  CBW_C1("%[nr]") CBW_C2 CBW_C3 CBW_C4("%[nr]")                      \
+  "v_add3_u32 %[o1], " XD ", " X3 ", %[km1]\n\t"                     \
+  "v_add_u32 %[o2], " XD ", " X4 "\n\t"                              \
+  CBW_C1("%[ni]") CBW_C2 CBW_C3 CBW_C4("%[ni]")                      \
+  "v_fma_f64 %[cr], %[nr], %[k2m50], %[kk]\n\t"                      \
+  "v_fma_f64 %[ci], %[ni], %[k2m50], %[kk]\n\t"
+#define CBW_PENDING_A(f1, f2, f3, f4) CBW_PENDING("%[a" #f1 "]", "%[a" #f2 "]", "%[a" #f3 "]", "%[a" #f4 "]", "%[ad]")
+#define CBW_PENDING_B(f1, f2, f3, f4) CBW_PENDING("%[b" #f1 "]", "%[b" #f2 "]", "%[b" #f3 "]", "%[b" #f4 "]", "%[bd]")
+
 // the ten bodies: generator A / B alternately, rot = 0 0 4 4 3 3 2 2 1 1 (logical word j in field (j + rot) % 5)
 #define CBW_BODY_A(f0, f1, f2, f3, f4) CBW_BODY("%[a" #f0 "]", "%[a" #f1 "]", "%[a" #f2 "]", "%[a" #f3 "]", "%[a" #f4 "]", "%[ad]")
 #define CBW_BODY_B(f0, f1, f2, f3, f4) CBW_BODY("%[b" #f0 "]", "%[b" #f1 "]", "%[b" #f2 "]", "%[b" #f3 "]", "%[b" #f4 "]", "%[bd]")
@@ -321,6 +340,11 @@ static_assert(362437u == 0x587c5u && 2u * 362437u == 0xb0f8au && 3u * 362437u ==
 struct Xorwow2 {
   Xorwow a, b;
 };
+// sample_coordinate2 (device_math.h) of two outputs that have already been drawn
+__device__ __forceinline__ double coordinate2_of(uint32_t v1, uint32_t v2) {
+  const double v = __builtin_fma((double) (v2 >> 11), 4294967296.0, (double) v1);
+  return __builtin_fma(v, 0x1p-50, 0x1p-50 - 4.0);
+}
 
 // Bodies in a row (at least one).  On entry a sample is pending in (cr, ci) and halves >= 1 draws are still to be
 // made; hs is the state (which generator the next draw takes, and its rotation).  q0_tail = q0_head + q0_count (only
@@ -329,13 +353,13 @@ struct Xorwow2 {
 // in every iteration and skips its work when `enable` is 0: the loop body then is straight-line code for the
 // compiler, and every such register has one definition per iteration (as conditional blocks the statements made it
 // keep two copies of the whole lane state and move one into the other around every stage).
-__device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double &cr, double &ci, uint32_t &halves,
+__device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, uint32_t &halves,
                                             uint32_t &hs, uint32_t q0_tail, uint32_t &q0_count, uint32_t q0_lds,
                                             uint32_t &n_rejected, uint32_t &n_too_fast, uint32_t &n_steps) {
   static_assert(kQ0Cap == 128, "ring mask and the 1024-byte distance of q0_ci in CBW_P4 / CBW_P6");
   unsigned long long save, m0, m1;
   uint32_t cnt, tmp, slot, t, u, o1, o2, acc0 = 0;
-  double a, r, i, x, q, f, nr, ni, kk;
+  double a, r, i, x, q, f, nr, ni, kk, cr, ci;
   enable = __builtin_amdgcn_readfirstlane(enable);
   halves = __builtin_amdgcn_readfirstlane(halves);
   hs = __builtin_amdgcn_readfirstlane(hs);
@@ -356,28 +380,39 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
       "s_mov_b64 exec, -1\n\t"
       "v_mov_b64 %[kk], %[k2m50]\n\t"
       "v_add_f64 %[kk], %[kk], -4.0\n\t"  // 2^-50 - 4, exactly
-      // enter at the body of the current state
+      // enter at the body of the current state, through the stub that makes its pending sample: drawn by the OTHER
+      // generator, whose words lie as the body after this one expects them
       "s_cmp_ge_u32 %[hs], 5\n\t"
       "s_cbranch_scc1 60f\n\t"
       "s_cmp_eq_u32 %[hs], 0\n\t"
-      "s_cbranch_scc1 10f\n\t"
+      "s_cbranch_scc1 30f\n\t"
       "s_cmp_eq_u32 %[hs], 1\n\t"
-      "s_cbranch_scc1 11f\n\t"
+      "s_cbranch_scc1 31f\n\t"
       "s_cmp_eq_u32 %[hs], 2\n\t"
-      "s_cbranch_scc1 12f\n\t"
+      "s_cbranch_scc1 32f\n\t"
       "s_cmp_eq_u32 %[hs], 3\n\t"
-      "s_cbranch_scc1 13f\n\t"
-      "s_branch 14f\n\t"
+      "s_cbranch_scc1 33f\n\t"
+      "s_branch 34f\n\t"
       "60:\n\t"
       "s_cmp_eq_u32 %[hs], 5\n\t"
-      "s_cbranch_scc1 15f\n\t"
+      "s_cbranch_scc1 35f\n\t"
       "s_cmp_eq_u32 %[hs], 6\n\t"
-      "s_cbranch_scc1 16f\n\t"
+      "s_cbranch_scc1 36f\n\t"
       "s_cmp_eq_u32 %[hs], 7\n\t"
-      "s_cbranch_scc1 17f\n\t"
+      "s_cbranch_scc1 37f\n\t"
       "s_cmp_eq_u32 %[hs], 8\n\t"
-      "s_cbranch_scc1 18f\n\t"
-      "s_branch 19f\n\t"
+      "s_cbranch_scc1 38f\n\t"
+      "s_branch 39f\n\t"
+      "30:\n\t" CBW_PENDING_B(1, 2, 3, 4) "s_branch 10f\n\t"   // (state 0 draws from A rot 0; B lies as in state 1: rot 0)
+      "31:\n\t" CBW_PENDING_A(0, 1, 2, 3) "s_branch 11f\n\t"   // (A as in state 2: rot 4)
+      "32:\n\t" CBW_PENDING_B(0, 1, 2, 3) "s_branch 12f\n\t"   // (B as in state 3: rot 4)
+      "33:\n\t" CBW_PENDING_A(4, 0, 1, 2) "s_branch 13f\n\t"   // (A as in state 4: rot 3)
+      "34:\n\t" CBW_PENDING_B(4, 0, 1, 2) "s_branch 14f\n\t"   // (B as in state 5: rot 3)
+      "35:\n\t" CBW_PENDING_A(3, 4, 0, 1) "s_branch 15f\n\t"   // (A as in state 6: rot 2)
+      "36:\n\t" CBW_PENDING_B(3, 4, 0, 1) "s_branch 16f\n\t"   // (B as in state 7: rot 2)
+      "37:\n\t" CBW_PENDING_A(2, 3, 4, 0) "s_branch 17f\n\t"   // (A as in state 8: rot 1)
+      "38:\n\t" CBW_PENDING_B(2, 3, 4, 0) "s_branch 18f\n\t"   // (B as in state 9: rot 1)
+      "39:\n\t" CBW_PENDING_A(1, 2, 3, 4) "s_branch 19f\n\t"   // (A as in state 0: rot 0)
       "10:\n\t" CBW_BODY_A(0, 1, 2, 3, 4) CBW_AFTER("81", "11:\n\t")  // rot 0
       CBW_BODY_B(0, 1, 2, 3, 4) CBW_AFTER("82", "12:\n\t")
       CBW_BODY_A(4, 0, 1, 2, 3) CBW_AFTER("83", "13:\n\t")            // rot 4
@@ -397,11 +432,12 @@ __device__ __forceinline__ void head_bodies(uint32_t enable, Xorwow2 &g, double 
         [steps] "+s"(n_steps), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt),
         [save] "=&s"(save), [tmp] "=&s"(tmp), [a] "=&v"(a), [r] "=&v"(r), [i] "=&v"(i), [x] "=&v"(x),
         [q] "=&v"(q), [slot] "=&v"(slot), [t] "=&v"(t), [u] "=&v"(u), [o1] "=&v"(o1), [o2] "=&v"(o2), [f] "=&v"(f),
-        [nr] "=&v"(nr), [ni] "=&v"(ni), [kk] "=&v"(kk), [cr] "+v"(cr), [ci] "+v"(ci),
+        [nr] "=&v"(nr), [ni] "=&v"(ni), [kk] "=&v"(kk), [cr] "=&v"(cr), [ci] "=&v"(ci),
         [a0] "+v"(g.a.x0), [a1] "+v"(g.a.x1), [a2] "+v"(g.a.x2), [a3] "+v"(g.a.x3), [a4] "+v"(g.a.x4), [ad] "+v"(g.a.d),
         [b0] "+v"(g.b.x0), [b1] "+v"(g.b.x1), [b2] "+v"(g.b.x2), [b3] "+v"(g.b.x3), [b4] "+v"(g.b.x4), [bd] "+v"(g.b.d)
       : [en] "s"(enable), [lds] "s"(q0_lds), [k2m50] "s"(0x1p-50), [k1] "s"(362437u), [k2] "s"(2u * 362437u),
-        [k3] "s"(3u * 362437u), [k4] "s"(4u * 362437u)
+        [k3] "s"(3u * 362437u), [k4] "s"(4u * 362437u), [km1] "s"(0u - 362437u), [km2] "s"(0u - 2u * 362437u),
+        [km3] "s"(0u - 3u * 362437u)
       : "vcc", "scc", "memory");
   // rejected: the lanes inside a region; escaped in HEAD (too fast): outside both regions and not among the survivors
   // (ctr has gone down by one per body that ran, past zero if all of them did)
@@ -1346,8 +1382,7 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   // wave-uniform scheduler state and statistics (scalar registers)
   uint32_t halves_left = 2u * a.samples_per_thread;  // draws still to make (A and B alternately)
   uint32_t hs = 0;                                   // head_bodies' state
-  uint32_t pending = 0;                              // 1: a drawn sample waits in (pend_cr, pend_ci) for its test
-  double pend_cr = 0.0, pend_ci = 0.0;
+  uint32_t pending = 0;                              // 1: a drawn sample waits for its test (in its generator's words: CBW_PENDING)
   int q0_head = 0, q0_count = 0;
   int q1_head = 0, q1_count = 0;
   int q2_head = 0, q2_count = 0;
@@ -1453,8 +1488,10 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
   // The launch's first sample: generator A, drawn in logical order, its words then rotated the way the bodies expect
   // them after one sample (outside the loop: the generator's registers are touched by head_bodies alone in there).
   if (halves_left != 0u) {
-    pend_cr = sample_coordinate2(rng.a);  // cudabrot.cu:392 (doubled, like everything below)
-    pend_ci = sample_coordinate2(rng.a);  // cudabrot.cu:393
+    (void) xorwow_next(rng.a);  // cudabrot.cu:392-393: four outputs; they stay in the generator's words (CBW_PENDING)
+    (void) xorwow_next(rng.a);
+    (void) xorwow_next(rng.a);
+    (void) xorwow_next(rng.a);
     rng.a = xorwow_rotated4(rng.a);
     halves_left--;
     hs = 1;
@@ -1547,11 +1584,17 @@ draw_wide_kernel(DrawArgs a) {                            // scatter's four (64 
       static_assert(kPrioHalves == 256, "CBW_AFTER ends the statement where halves % 256 == 0");
       if (bodies && (halves_left & (kPrioHalves - 1u)) == 0u) post_progress_and_set_priority(halves_left);
       uint32_t count = (uint32_t) q0_count;
-      if (bodies) head_bodies(1u, rng, pend_cr, pend_ci, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
+      if (bodies) head_bodies(1u, rng, halves_left, hs, (uint32_t) (q0_head + q0_count), count,
                   q0_lds, f_rejected, f_too_fast, f_steps);  // survivors -> Q0
       q0_count = (int) count;
       if (do_head && !bodies) {  // the launch's last sample: its test alone (cudabrot.cu:398, 326-337)
-        Orbit o = {pend_cr, pend_ci, pend_cr, pend_ci};
+        // (its outputs, out of its generator's words: hs = 2 p + g -- A has drawn p + g samples, B p; the last draw was
+        // A's if g == 1)
+        const uint32_t from_b = (hs & 1u) ^ 1u, drawn = (hs >> 1) + (from_b ? 0u : 1u);
+        const Xorwow lg = xorwow_unrotate(from_b ? rng.b : rng.a, (5u - drawn % 5u) % 5u);
+        const double p_cr = coordinate2_of(lg.d + lg.x1 - 3u * 362437u, lg.d + lg.x2 - 2u * 362437u);
+        const double p_ci = coordinate2_of(lg.d + lg.x3 - 362437u, lg.d + lg.x4);
+        Orbit o = {p_cr, p_ci, p_cr, p_ci};
 #ifdef CB_BURNING_SHIP
         const bool alive = true;  // cudabrot.cu:397-399: no shortcut in this variant
 #else
