@@ -91,7 +91,7 @@ def newest_summary(samples_per_step, workload_prefix="C3"):
     import glob
 
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]*_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[2-9]*_summary.json"))):
         try:
             s = json.load(open(f))
             cfg = s["bench_line"]["config"]
@@ -102,9 +102,9 @@ def newest_summary(samples_per_step, workload_prefix="C3"):
     return best
 
 
-def recorded_traffic(samples_per_step):
+def recorded_traffic(samples_per_step, workload_prefix="C3"):
     """HBM-side bytes per launch of the draw kernel and of the scatter kernels from that summary."""
-    best = newest_summary(samples_per_step)
+    best = newest_summary(samples_per_step, workload_prefix)
     if not best:
         return None
     f, s = best
@@ -117,13 +117,13 @@ def recorded_traffic(samples_per_step):
         return None
 
 
-def recorded_valu_busy(samples_per_step, kernel_prefix="draw_"):
+def recorded_valu_busy(samples_per_step, kernel_prefix="draw_", workload_prefix="C3"):
     """Vector-issue utilisation of the draw kernel from the counters of that summary: SQ_INSTS_VALU (wave
     instructions per dispatch) x 4 cycles (a SIMD issues one fp64 wave-instruction per 4 cycles) over the SIMD
     cycles of the SAME profiled dispatch (1024 SIMDs x its duration x clock) -- bounded by 1, unlike `frac`.
     Both at the 2.4 GHz spec clock and at the clock the counters themselves give (GRBM_GUI_ACTIVE / 8 XCDs /
     duration: MI355X_MICROARCH.md, DVFS give-back)."""
-    best = newest_summary(samples_per_step)
+    best = newest_summary(samples_per_step, workload_prefix)
     if not best:
         return None
     f, s = best
@@ -346,7 +346,9 @@ def other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread, step
     windows = C5_WINDOWS if name == "C5" else [(max_iter, min_iter)]
     job = Job(cb, torch, dev, w, h, windows, C5_BOX if name == "C5" else None, 0, threads, samples_per_thread)
     try:
-        draw_ms, flush_ms, _ = job.sequential_leg(np, launches=3, timed_from=1)
+        before = job.counter_values(np)
+        draw_ms, flush_ms, incr = job.sequential_leg(np, launches=3, timed_from=1)
+        seq = job.counter_values(np)
         job.step()
         job.step(0)
         torch.cuda.synchronize()
@@ -372,6 +374,34 @@ def other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread, step
             "scatter_alone_ms": round(sum(flush_ms) / len(flush_ms), 3),
             "workspace_gib": round(job.ws_bytes / 2.0 ** 30, 2),
             "increments_per_sample": round(cnt["increments"] / cnt["samples"], 4),
+        }
+        # The two rooflines of this config, as for the headline one: the draw launch against the fp64
+        # vector peak -- 10 algorithmic flops per EXECUTED iteration, counted in-kernel over the three launches and
+        # the drain of the sequential leg, over the alone-time of a launch -- and the scatter kernels against HBM --
+        # 16 algorithmic bytes per increment over their alone-time.  valu_busy / traffic: from the newest committed
+        # counter summary of this config (profiles/, tools/gpu_profile.sh with CONFIG=<name>), when there is one.
+        executed = (seq["iterate_steps"] - before["iterate_steps"]) - (seq["skipped_steps"] - before["skipped_steps"]) + \
+                   (seq["replay_steps"] - before["replay_steps"])
+        launches = max((seq["samples"] - before["samples"]) / float(threads * samples_per_thread), 1.0)
+        draw_s = out["draw_alone_ms"] * 1e-3
+        tflops = executed / launches * FLOPS_PER_ITERATION / draw_s / 1e12
+        scatter_gbps = (sum(incr) / len(incr)) * BYTES_PER_INCREMENT / (out["scatter_alone_ms"] * 1e-3) / 1e9
+        busy = recorded_valu_busy(threads * samples_per_thread, workload_prefix=name)
+        traffic = recorded_traffic(threads * samples_per_thread, workload_prefix=name)
+        out["roofline"] = {
+            "bound": "valu_fp64", "achieved": round(tflops, 3), "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_FP64_VECTOR_TFLOPS, 4),
+            "executed_iterations_per_sample": round(executed / launches / (threads * samples_per_thread), 3),
+            "valu_busy": busy["valu_busy"] if busy else None,
+            "sq_insts_valu_per_launch": busy["sq_insts_valu_per_launch"] if busy else None,
+            "valu_busy_source": busy["valu_busy_source"] if busy else None,
+            "traffic": traffic["draw"] if traffic else None,
+        }
+        out["roofline_scatter"] = {
+            "bound": "hbm", "achieved": round(scatter_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+            "frac": round(scatter_gbps / PEAK_HBM_GBPS, 4),
+            "traffic": traffic["scatter"] if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
         }
     finally:
         del job
@@ -513,6 +543,13 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if world > 1:
+        # every rank must have used the (same) interior map: a rank that ran without it is 15 % slower, and the weakest
+        # rank is the job's time (the map is copied to each device once per process, on its first launch there)
+        lv = torch.tensor([interior_map_level, -interior_map_level], dtype=torch.int64, device=dev)
+        dist.all_reduce(lv, op=dist.ReduceOp.MIN)
+        assert int(lv[0].item()) == interior_map_level == -int(lv[1].item()), \
+            "the ranks disagree on the interior map: %d here, %d..%d over the job" % (interior_map_level, int(lv[0].item()), -int(lv[1].item()))
 
     # after the clock has stopped: the one collective of the path, and consistency checks
     c_local = counters.clone()

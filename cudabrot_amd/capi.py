@@ -145,6 +145,7 @@ def _load():
         "cb_debug_knob": (C.c_char_p, [C.c_char_p]),
         "cb_debug_last_draw_kernel": (i32, []),
         "cb_debug_interior_map_level": (i32, []),
+        "cb_renderer_interior_map_level": (i32, [vp]),
         "cb_recompute_pixel_deltas": (i32, [dims_p, C.POINTER(C.c_char_p)]),
         "cb_rng_state_bytes": (C.c_size_t, [u32]),
         "cb_initialize_rng": (i32, [u64, u64, u32, vp, vp]),
@@ -185,7 +186,7 @@ def _load():
 
 lib = _load()
 EXPORTED_SYMBOLS = (
-    "cb_abi_version cb_error_string cb_debug_knob cb_debug_last_draw_kernel cb_debug_interior_map_level cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
+    "cb_abi_version cb_error_string cb_debug_knob cb_debug_last_draw_kernel cb_debug_interior_map_level cb_renderer_interior_map_level cb_recompute_pixel_deltas cb_rng_state_bytes cb_initialize_rng "
     "cb_scatter_workspace_bytes cb_scatter_workspace_bytes_channels cb_carry_bytes cb_draw_buddhabrot cb_flush_scatter cb_renderer_create "
     "cb_renderer_render_passes cb_renderer_finish "
     "cb_renderer_read_histogram "

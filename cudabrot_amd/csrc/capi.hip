@@ -132,12 +132,13 @@ const DeviceMap *device_map(MapKind kind) {
 // the lock-step kernel and the other forms ignore it): where orbits may be retired early at all -- not the Burning
 // Ship, not the full-iterate variants (CUDABROT_AMD_NO_INTERIOR_MAP=1, a test knob: never).  0, or an error: a map that
 // should be there and is not is never passed over in silence.
+bool wants_interior_map(bool ship, int base_variant) {
+  return !(ship || base_variant == CB_KERNEL_FULL_ITERATE || base_variant == CB_KERNEL_SIMPLE ||
+           cb_debug_knob("CUDABROT_AMD_TIMED_FULL") != nullptr || cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") != nullptr);
+}
 int attach_interior_map(cb::DrawArgs &a, bool ship, int base_variant) {
   g_interior_level.store(0, std::memory_order_relaxed);
-  if (ship || base_variant == CB_KERNEL_FULL_ITERATE || base_variant == CB_KERNEL_SIMPLE ||
-      cb_debug_knob("CUDABROT_AMD_TIMED_FULL") != nullptr || cb_debug_knob("CUDABROT_AMD_NO_INTERIOR_MAP") != nullptr) {
-    return 0;
-  }
+  if (!wants_interior_map(ship, base_variant)) return 0;
   const DeviceMap *m = device_map(kMapInterior);
   if (!m) return (int) hipErrorInvalidValue;
   a.interior_map = m->d_bytes;
@@ -280,6 +281,9 @@ struct cb_renderer {
   // fused multi-channel render: n_channels > 0 windows, d_hist holds that many planes
   int n_channels;
   cb_iteration_control windows[CB_MAX_CHANNELS];
+  // the level of the interior map this renderer's last launch used (0: none) -- its own record: the process-wide
+  // cb_debug_interior_map_level is whichever rank's launch came last
+  int interior_level;
 };
 
 namespace {
@@ -308,6 +312,12 @@ int enqueue_launch(cb_renderer *r, uint32_t passes, int kernel_variant) {
                             wave ? r->d_carry : nullptr, r->stream);
   }
   if (rc) return rc;
+  {
+    const bool ship = (kernel_variant & CB_KERNEL_FLAG_BURNING_SHIP) != 0;
+    const int base = kernel_variant & ~(CB_KERNEL_FLAG_BURNING_SHIP | CB_KERNEL_FLAG_DRAIN);
+    const DeviceMap *m = wants_interior_map(ship, base) ? device_map(kMapInterior) : nullptr;
+    r->interior_level = m ? (int) m->level : 0;
+  }
   if (wave && r->d_carry) {
     r->carry_pending = passes != 0;
     r->carry_variant = kernel_variant;
@@ -362,21 +372,39 @@ __global__ void __launch_bounds__(256) add_histogram_kernel(unsigned long long *
 
 // ncclReduce of the renderers' histograms onto renderers[0] (one device each).  librccl is opened on
 // first use; the symbols are the ones rccl.h declares.
+std::mutex g_rccl_mutex;
+decltype(&ncclCommDestroy) g_comm_destroy = nullptr;
+std::vector<int> g_comm_devices;   // the devices of the cached communicators ...
+std::vector<ncclComm_t> g_comms;   // ... one per device, kept until one of their renderers goes (below)
+
+// The cached communicators end with the first renderer of their set that is destroyed (cb_renderer_destroy): nothing of
+// RCCL's is left to the teardown of the process.
+void release_communicators_with(int device) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  bool mine = false;
+  for (int d : g_comm_devices) mine = mine || d == device;
+  if (!mine || !g_comm_destroy) return;
+  for (ncclComm_t c : g_comms) (void) g_comm_destroy(c);
+  g_comms.clear();
+  g_comm_devices.clear();
+}
+
 int rccl_reduce_to_root(cb_renderer *const *renderers, int n, size_t count) {
   static void *lib = nullptr;
   static decltype(&ncclCommInitAll) comm_init_all = nullptr;
-  static decltype(&ncclCommDestroy) comm_destroy = nullptr;
   static decltype(&ncclGroupStart) group_start = nullptr;
   static decltype(&ncclGroupEnd) group_end = nullptr;
   static decltype(&ncclReduce) reduce = nullptr;
-  static std::mutex mutex;
-  std::lock_guard<std::mutex> lock(mutex);
+  decltype(&ncclCommDestroy) &comm_destroy = g_comm_destroy;
+  std::vector<int> &comm_devices = g_comm_devices;
+  std::vector<ncclComm_t> &comms = g_comms;
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (!lib) {
     lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) return (int) hipErrorSharedObjectInitFailed;
     comm_init_all = reinterpret_cast<decltype(comm_init_all)>(dlsym(lib, "ncclCommInitAll"));
-    comm_destroy = reinterpret_cast<decltype(comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+    comm_destroy = reinterpret_cast<decltype(&ncclCommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     group_start = reinterpret_cast<decltype(group_start)>(dlsym(lib, "ncclGroupStart"));
     group_end = reinterpret_cast<decltype(group_end)>(dlsym(lib, "ncclGroupEnd"));
     reduce = reinterpret_cast<decltype(reduce)>(dlsym(lib, "ncclReduce"));
@@ -386,10 +414,8 @@ int rccl_reduce_to_root(cb_renderer *const *renderers, int n, size_t count) {
   }
   std::vector<int> devices(n);
   for (int k = 0; k < n; ++k) devices[k] = renderers[k]->device;
-  // One communicator per set of devices, kept for the life of the process: creating it costs far more than the
-  // reduce (a bootstrap over all ranks), and a renderer set is reduced at every checkpoint.
-  static std::vector<int> comm_devices;
-  static std::vector<ncclComm_t> comms;
+  // One communicator per set of devices, kept while its renderers live: creating it costs far more than the reduce (a
+  // bootstrap over all ranks), and a renderer set is reduced at every checkpoint.
   if (comm_devices != devices) {
     for (ncclComm_t c : comms) (void) comm_destroy(c);
     comms.assign((size_t) n, nullptr);
@@ -433,6 +459,7 @@ int cb_abi_version(void) { return CB_ABI_VERSION; }
 
 int cb_debug_last_draw_kernel(void) { return g_last_draw_kernel.load(std::memory_order_relaxed); }
 int cb_debug_interior_map_level(void) { return g_interior_level.load(std::memory_order_relaxed); }
+int cb_renderer_interior_map_level(const cb_renderer *r) { return r ? r->interior_level : 0; }
 
 const char *cb_error_string(int code) {
   if (code == 0) return "no error";
@@ -830,6 +857,7 @@ void cb_renderer_destroy(cb_renderer *r) {
   (void) hipSetDevice(r->device);
   if (r->stream) (void) hipStreamSynchronize(r->stream);
   if (r->flush_stream) (void) hipStreamSynchronize(r->flush_stream);
+  release_communicators_with(r->device);  // (cached by cb_renderers_reduce for a set this renderer may belong to)
   (void) hipFree(r->d_hist);
   (void) hipFree(r->d_states);
   (void) hipFree(r->d_counters);

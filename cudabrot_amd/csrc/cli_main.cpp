@@ -598,12 +598,13 @@ class Run {
         }
         if (by_clock && slowest >= 1) {
           const double per_pass = elapsed / (double) slowest;  // the slowest rank's pace
-          double ahead = 2.0 * launch_seconds_;
-          if (cfg_.seconds_to_run >= 0 && cfg_.seconds_to_run - elapsed < ahead) ahead = cfg_.seconds_to_run - elapsed;
+          // whole launches of cb_renderer, to the end: the clock acts at the granularity of a batch, as it does on one GPU
+          // (a budget that shrank with the time left made the ranks issue 1-pass launches, which drain badly)
+          const double ahead = 2.0 * launch_seconds_;
           long lead = per_pass > 0 ? (long) (ahead / per_pass) : lead_min;
           if (lead > 4096) lead = 4096;
-          if (lead > lead_min) lead -= lead % lead_min;
-          if (lead < 1) lead = 1;
+          lead -= lead % lead_min;
+          if (lead < lead_min) lead = lead_min;
           if (slowest + lead > sh.granted) {
             sh.granted = slowest + lead;
             sh.cv.notify_all();
@@ -672,8 +673,12 @@ class Run {
       c.skipped_steps += o.skipped_steps;
       c.status |= o.status;
     }
+    // the level of the interior map every rank's last launch used (0: none), rank by rank
+    std::string levels = std::to_string(cb_renderer_interior_map_level(renderer_));
+    for (cb_renderer *p : peers_) levels += ", " + std::to_string(cb_renderer_interior_map_level(p));
+    fprintf(stderr, "{\"interior_map_levels\": [%s], ", levels.c_str());
     fprintf(stderr,
-            "{\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
+            "\"samples\": %llu, \"rejected\": %llu, \"never_escaped\": %llu, \"too_fast\": %llu, "
             "\"recorded\": %llu, \"iterate_steps\": %llu, \"replay_steps\": %llu, "
             "\"increments\": %llu, \"skipped_steps\": %llu, \"status\": %llu, \"cycles_head\": %llu, "
             "\"cycles_long\": %llu, "

@@ -294,6 +294,9 @@ int cb_debug_last_draw_kernel(void);
  * c-plane whose samples provably never escape: the draw kernel retires them without iterating; made and proven by
  * tools/interior_map.c, embedded in the library), 0 if it used none.  Results do not depend on it. */
 int cb_debug_interior_map_level(void);
+/* The same for ONE renderer's last launch (with several ranks in a process the process-wide figure above is whichever
+ * rank's launch came last; the map itself is copied to every device once per process, on its first launch there). */
+int cb_renderer_interior_map_level(const cb_renderer *r);
 
 #ifdef __cplusplus
 }

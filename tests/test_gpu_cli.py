@@ -343,3 +343,17 @@ def test_invalid_device_reports_like_the_reference_and_exits_one(exe):
     r = run(exe, "-d", "99", "--passes", "1", "-w", "16", "-h", "16", "-o", os.devnull)
     assert r.returncode == 1
     assert r.stdout.strip().split("\n")[-1].startswith("CUDA error ")   # cudabrot.cu:137, wording kept
+
+
+def test_eight_ranks_all_use_the_interior_map(exe, tmp_path):
+    """keep the first 8-GPU run boring -- every rank's launches must use the (embedded) interior map; the
+    record is the renderer's own (cb_renderer_interior_map_level), not the process-wide figure that rank threads
+    overwrite.  --stats prints it rank by rank."""
+    import json
+
+    env = dict(os.environ, CUDABROT_AMD_FAKE_GPUS="1")
+    r = run(exe, "--gpus", "8", "--passes", "2", "-w", "256", "-h", "256", "-m", "2000", "-o", os.devnull, "--stats", env=env)
+    assert r.returncode == 0, r.stdout
+    stats = json.loads([l for l in r.stderr.splitlines() if l.startswith("{")][-1])
+    assert stats["interior_map_levels"] == [12] * 8, stats
+    assert stats["status"] == 0 and stats["skipped_steps"] > 0 and stats["samples"] == 8 * T * 50 * 2

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Bench + rocprofv3 evidence for profiles/: one bench line, a kernel-trace/stats run and separate
 # PMC passes (counters never combined with trace domains other than kernel-trace).
-# Usage: tools/gpu_profile.sh <tag>     e.g. r01
+# Usage: [CONFIG=C4] tools/gpu_profile.sh <tag>     e.g. r01   (CONFIG: another BASELINE config than the headline C3)
 set -u
 TAG=${1:-r01}
+CONFIG=${CONFIG:-C3}
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -16,8 +17,9 @@ run() {  # run <seconds> <logfile> <cmd...>
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: stopping session"; exit 1; fi
   return 0
 }
-BENCH_ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
-run 400 "$OUT/bench_full.json" python3 bench.py
+BENCH_ARGS="--config $CONFIG --steps 4 --warmup 1 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
+if [ "$CONFIG" = C3 ]; then run 400 "$OUT/bench_full.json" python3 bench.py
+else run 400 "$OUT/bench_full.json" python3 bench.py --config $CONFIG --steps 12 --warmup 2 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs; fi
 run 300 "$OUT/stats.log" rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $BENCH_ARGS
 run 300 "$OUT/pmc_fetch.log" rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 bench.py $BENCH_ARGS
 run 300 "$OUT/pmc_write.log" rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 bench.py $BENCH_ARGS

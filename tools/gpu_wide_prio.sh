@@ -3,7 +3,7 @@
 # per setting (make EXTRA=-D...) and prints the bench's short line.   usage: tools/gpu_wide_prio.sh "b,a,s" ...
 set -u
 mkdir -p gpurun_out
-B="--steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
+B="--config ${CONFIG:-C3} --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs"
 for setting in "$@"; do
   IFS=, read -r pb pa ps pr pg <<< "$setting"   # draw behind, draw ahead, sort i/o, sort rank, gather
   pr=${pr:-$ps}; pg=${pg:-$ps}
