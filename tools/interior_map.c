@@ -34,7 +34,7 @@
 //                                            periodicity check alone and with the map in front of it
 //   ./interior_map check LEVEL map.bin N     N samples drawn INSIDE marked cells, iterated to max_iter 20000 with the
 //                                            reference's arithmetic: how many escape (must be 0)
-//   ./interior_map verify LEVEL map.bin D depths.bin [SAMPLE SKIP_BELOW SEED]
+//   ./interior_map verify LEVEL map.bin D depths.bin [SAMPLE SKIP_BELOW SEED [PER_DEPTH]]
 //                                            re-prove the marked cells of a kept map (all of them, noting the depth each
 //                                            proof needed in depths.bin; or a stratified sample against those notes)
 #include <math.h>
@@ -216,12 +216,14 @@ int main(int argc, char **argv) {
     // their indices (0xff: not proven yet).  A sidecar that exists is continued (cells with a depth are skipped unless
     // SAMPLE is given); SAMPLE > 0: re-prove only the cells whose noted depth exceeds SKIP_BELOW plus SAMPLE others drawn
     // with SEED (the stratified check of tests/test_interior_map.py), changing nothing in the file.
-    //   ./interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED]
-    if (argc < 6) { fprintf(stderr, "usage: interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED]\n"); return 2; }
+    //   ./interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED [PER_DEPTH]]
+    // (PER_DEPTH: of the cells above SKIP_BELOW only so many per depth, drawn at random -- a test that fits minutes)
+    if (argc < 6) { fprintf(stderr, "usage: interior_map verify LEVEL map.bin DEPTH depths.bin [SAMPLE SKIP_BELOW SEED [PER_DEPTH]]\n"); return 2; }
     const int depth = atoi(argv[4]);
     const long sample = argc > 6 ? atol(argv[6]) : 0;
     const int skip_below = argc > 7 ? atoi(argv[7]) : 3;
     if (argc > 8) rng_state ^= (uint64_t) atol(argv[8]) * 0x9e3779b97f4a7c15ull;
+    const long per_depth = argc > 9 ? atol(argv[9]) : -1;  // at most so many of the cells of every depth above SKIP_BELOW (-1: all)
     const double s = ldexp(1.0, -level);
     long *marked = malloc(sizeof(long) * ((size_t) cells / 8 + 64));
     long nm = 0;
@@ -238,7 +240,22 @@ int main(int argc, char **argv) {
     uint8_t *todo = calloc((size_t) nm + 1, 1);
     long n_todo = 0;
     if (sample > 0) {
-      for (long k = 0; k < nm; ++k) if (used[k] == 0xff || used[k] > skip_below) { todo[k] = 1; ++n_todo; }
+      if (per_depth < 0) {
+        for (long k = 0; k < nm; ++k) if (used[k] == 0xff || used[k] > skip_below) { todo[k] = 1; ++n_todo; }
+      } else {  // a random stratum per depth: reservoir sampling, depth by depth
+        for (int d = skip_below + 1; d <= 255; ++d) {
+          long seen = 0, *pick = malloc(sizeof(long) * (size_t) (per_depth + 1));
+          for (long k = 0; k < nm; ++k) {
+            if (used[k] != (uint8_t) d) continue;
+            if (seen < per_depth) pick[seen] = k;
+            else { const long j = (long) (uniform01() * (double) (seen + 1)); if (j < per_depth) pick[j] = k; }
+            ++seen;
+          }
+          for (long j = 0; j < (seen < per_depth ? seen : per_depth); ++j) if (!todo[pick[j]]) { todo[pick[j]] = 1; ++n_todo; }
+          free(pick);
+          if (d == 254) break;
+        }
+      }
       for (long k = 0; k < sample; ++k) {
         const long j = (long) (uniform01() * (double) nm);
         if (j < nm && !todo[j]) { todo[j] = 1; ++n_todo; }
