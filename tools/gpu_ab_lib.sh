@@ -20,7 +20,7 @@ for k in $(seq $rounds); do
   for v in $name mine; do
     if [ $v = mine ]; then cp gpurun_out/lib_mine.so cudabrot_amd/libcudabrot_amd.so; cp gpurun_out/capi_mine.py cudabrot_amd/capi.py; cp gpurun_out/init_mine.py cudabrot_amd/__init__.py; rm -f cudabrot_amd/interior_map.bin
     else cp tools/_ab/$v/* cudabrot_amd/; fi
-    timeout -k 10 150 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs > gpurun_out/ab_$v.log 2>&1
+    timeout -k 10 150 python3 bench.py --config ${CONFIG:-C3} --steps ${STEPS:-20} --warmup 5 --no-cpu-baseline --no-reference --no-full-iterate --no-other-configs > gpurun_out/ab_$v.log 2>&1
     line $v gpurun_out/ab_$v.log
   done
 done
