@@ -34,10 +34,14 @@
 //                                            periodicity check alone and with the map in front of it
 //   ./interior_map check LEVEL map.bin N     N samples drawn INSIDE marked cells, iterated to max_iter 20000 with the
 //                                            reference's arithmetic: how many escape (must be 0)
+//   ./interior_map deepen LEVEL map.bin D depths.bin out_map.bin out_depths.bin SECONDS
+//                                            try the unmarked cells that touch a marked one with D levels of quarters
+//                                            (one more than the map was made with): an anytime run, see there
 //   ./interior_map verify LEVEL map.bin D depths.bin [SAMPLE SKIP_BELOW SEED [PER_DEPTH]]
 //                                            re-prove the marked cells of a kept map (all of them, noting the depth each
 //                                            proof needed in depths.bin; or a stratified sample against those notes)
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -173,7 +177,7 @@ static int sched(unsigned c) {  // the kernel's schedule of saved points: chunk 
 static inline uint64_t bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
 
 int main(int argc, char **argv) {
-  if (argc < 4) { fprintf(stderr, "usage: interior_map make|model|check|verify LEVEL file [N]\n"); return 2; }
+  if (argc < 4) { fprintf(stderr, "usage: interior_map make|model|check|verify|deepen LEVEL file [N]\n"); return 2; }
   const int level = atoi(argv[2]);
   const long cols = cols_of(level), rows = rows_of(level), cells = cols * rows;
   const size_t bytes = (size_t) (cells + 7) / 8;
@@ -306,6 +310,110 @@ int main(int argc, char **argv) {
     if (by_depth[16]) printf(" unknown:%ld", by_depth[16]);
     printf("\n");
     return failed != 0 || mismatched != 0;
+  }
+  if (!strcmp(argv[1], "deepen")) {
+    // One more level of quarters where it can pay: the UNMARKED cells that touch a marked one (the boundary layer the
+    // kept budget left), each tried with DEPTH levels; a cell that is proven is marked, and its depth noted.  Every cell
+    // stands on its own proof, so the run can be stopped at any time (SECONDS: no new cell is begun after that; the two
+    // files are rewritten every ten minutes): what has been added by then is a valid, larger map.
+    //   ./interior_map deepen LEVEL map.bin DEPTH depths.bin out_map.bin out_depths.bin SECONDS
+    if (argc < 9) { fprintf(stderr, "usage: interior_map deepen LEVEL map.bin DEPTH depths.bin out_map.bin out_depths.bin SECONDS\n"); return 2; }
+    const int depth = atoi(argv[4]);
+    const double budget = atof(argv[8]);
+    const double s = ldexp(1.0, -level);
+    long nm = 0;
+    for (long k = 0; k < cells; ++k) nm += (map[k >> 3] >> (k & 7)) & 1;
+    uint8_t *cell_depth = malloc((size_t) cells);  // per CELL here (0xff: not marked)
+    memset(cell_depth, 0xff, (size_t) cells);
+    {
+      FILE *g = fopen(argv[5], "rb");
+      uint32_t h4[4];
+      uint8_t *used = malloc((size_t) nm + 1);
+      if (!g || fread(h4, 1, 16, g) != 16 || h4[0] != 0x44494243u || h4[1] != (uint32_t) level || h4[2] != (uint32_t) nm ||
+          fread(used, 1, (size_t) nm, g) != (size_t) nm) { fprintf(stderr, "%s: not the depths of this map\n", argv[5]); return 1; }
+      fclose(g);
+      long j = 0;
+      for (long k = 0; k < cells; ++k) if ((map[k >> 3] >> (k & 7)) & 1) cell_depth[k] = used[j++];
+      free(used);
+    }
+    // candidates: unmarked, a marked cell among the eight around it, the centre inside |c| <= 2 and outside cardioid and bulb
+    long *cand = malloc(sizeof(long) * (size_t) (cells / 16 + 64));
+    long nc = 0;
+    for (long y = 0; y < rows; ++y) {
+      for (long x = 0; x < cols; ++x) {
+        const long k = y * cols + x;
+        if (k == 0 || ((map[k >> 3] >> (k & 7)) & 1)) continue;
+        int touches = 0;
+        for (int dy = -1; dy <= 1 && !touches; ++dy) {
+          for (int dx = -1; dx <= 1; ++dx) {
+            const long yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) continue;
+            const long kk = yy * cols + xx;
+            if ((map[kk >> 3] >> (kk & 7)) & 1) { touches = 1; break; }
+          }
+        }
+        if (!touches) continue;
+        const double c0r = RE_MIN + (x + 0.5) * s, c0i = (y + 0.5) * s;
+        if (c0r * c0r + c0i * c0i > 4.0 || in_cardioid_or_bulb(c0r, c0i)) continue;
+        if (nc < cells / 16) cand[nc++] = k;
+      }
+    }
+    for (long k = nc - 1; k > 0; --k) {  // a random order: a run that is stopped has tried a uniform sample
+      const long j = (long) (uniform01() * (double) (k + 1));
+      const long t = cand[k]; cand[k] = cand[j]; cand[j] = t;
+    }
+    printf("%ld marked cells, %ld candidates at depth <= %d, %.0f s\n", nm, nc, depth, budget);
+    fflush(stdout);
+    const double t_begin = omp_get_wtime();
+    double t_saved = t_begin;
+    long added = 0, tried = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (long j = 0; j < nc; ++j) {
+      if (omp_get_wtime() - t_begin > budget) continue;
+      const long k = cand[j], x = k % cols, y = k / cols;
+      int u = 0;
+      const int ok = verify_square_depth(RE_MIN + (x + 0.5) * s, (y + 0.5) * s, 0.5 * s, depth, &u) == 1;
+#pragma omp critical
+      {
+        ++tried;
+        if (ok) {
+          map[k >> 3] |= (uint8_t) (1u << (k & 7));
+          cell_depth[k] = (uint8_t) u;
+          ++added;
+        }
+        const double now = omp_get_wtime();
+        if (now - t_saved > 600.0 || tried == nc) {
+          t_saved = now;
+          const uint32_t header[4] = {0x4d494243u, (uint32_t) level, (uint32_t) cols, (uint32_t) rows};
+          const uint32_t h4[4] = {0x44494243u, (uint32_t) level, (uint32_t) (nm + added), (uint32_t) depth};
+          FILE *f = fopen(argv[6], "wb"), *g = fopen(argv[7], "wb");
+          if (f && g) {
+            fwrite(header, 1, 16, f);
+            fwrite(map, 1, bytes, f);
+            fwrite(h4, 1, 16, g);
+            for (long c = 0; c < cells; ++c) if (cell_depth[c] != 0xff) fputc(cell_depth[c], g);
+          }
+          if (f) fclose(f);
+          if (g) fclose(g);
+          printf("%.0f s: %ld of %ld tried, %ld added\n", now - t_begin, tried, nc, added);
+          fflush(stdout);
+        }
+      }
+    }
+    {
+      const uint32_t header[4] = {0x4d494243u, (uint32_t) level, (uint32_t) cols, (uint32_t) rows};
+      const uint32_t h4[4] = {0x44494243u, (uint32_t) level, (uint32_t) (nm + added), (uint32_t) depth};
+      FILE *f = fopen(argv[6], "wb"), *g = fopen(argv[7], "wb");
+      if (!f || !g) { perror("output"); return 1; }
+      fwrite(header, 1, 16, f);
+      fwrite(map, 1, bytes, f);
+      fwrite(h4, 1, 16, g);
+      for (long c = 0; c < cells; ++c) if (cell_depth[c] != 0xff) fputc(cell_depth[c], g);
+      fclose(f);
+      fclose(g);
+    }
+    printf("tried %ld of %ld candidates, added %ld cells: %ld marked\n", tried, nc, added, nm + added);
+    return 0;
   }
   const long n = argc > 4 ? atol(argv[4]) : 1000000;
   const int max_iter = 20000, start = 20, chunk = 60;
