@@ -1177,7 +1177,14 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
                      b.e_chan_mask == 0u;
   const bool few = b.n_tiles <= kFewTilesMax;
   uint32_t skip_lean = 0u;
+#ifndef CB_SORT_LDS_PAD  // (a measuring switch: more LDS per sort workgroup than it needs -- 16384 leaves room for ONE per CU)
+#define CB_SORT_LDS_PAD 0
+#endif
+#ifndef CB_GATHER_LDS_PAD  // (likewise for the gather, whose 64 KiB tile is static)
+#define CB_GATHER_LDS_PAD 0
+#endif
   const auto launch_sort = [&](auto kernel, size_t lds_bytes) -> hipError_t {
+    lds_bytes += CB_SORT_LDS_PAD;
     // per call: the attribute belongs to the current device
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);  // ~74 KiB of the 160 per CU
@@ -1220,11 +1227,11 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   const unsigned long long by_cap = rows * b.max_regions / b.slice_regions;  // slices of the largest size
   const unsigned long long slices = b.n_tiles + (by_cap > kSliceTargetGroups ? by_cap : kSliceTargetGroups) + 1ull;
   if (b.two_level) {
-    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsNarrow>, dim3((uint32_t) slices), dim3(kAccThreadsNarrow), 0,
-                       stream, b, hist, w, h);
+    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsNarrow>, dim3((uint32_t) slices), dim3(kAccThreadsNarrow),
+                       CB_GATHER_LDS_PAD, stream, b, hist, w, h);
   } else {
-    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsWide>, dim3((uint32_t) slices), dim3(kAccThreadsWide), 0,
-                       stream, b, hist, w, h);
+    hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsWide>, dim3((uint32_t) slices), dim3(kAccThreadsWide),
+                       CB_GATHER_LDS_PAD, stream, b, hist, w, h);
   }
   return hipGetLastError();
 }
