@@ -1149,9 +1149,24 @@ BinLayout make_bin_layout(void *workspace, size_t bytes, int w, int h, uint32_t 
   return b;
 }
 
+// One wave that sleeps: the head of the scatter's chain.  The chain runs beside the NEXT draw launch, on the other stream,
+// and both are released by the same event; whichever reaches the dispatcher first gets the empty CUs.  If that is this
+// chain's first kernel (2048 one-wave workgroups, a few registers each, all over the GPU), the draw's waves -- 128
+// registers each, two per SIMD -- land behind them, and what they leave free on a SIMD is no longer one block of 256
+// registers: the region sort's workgroup (four waves of 64 on every SIMD of a CU) then fits nowhere until draw waves
+// exit, i.e. the sort runs AFTER the draw instead of beside it (C4: a step of 12.1 ms instead of 9.4, every other step).
+#ifndef CB_CHAIN_DELAY_US
+#define CB_CHAIN_DELAY_US 40
+#endif
+__global__ void __launch_bounds__(64) chain_delay_kernel(uint32_t ticks) {
+  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  for (uint32_t turn = 0; turn < 4096u && wall_clock64() - t0 < ticks; ++turn) __builtin_amdgcn_s_sleep(32);
+}
+
 hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, int w, int h,
                                  hipStream_t stream) {
   if (!b.enabled) return hipSuccess;
+  if (CB_CHAIN_DELAY_US) hipLaunchKernelGGL(chain_delay_kernel, dim3(1), dim3(64), 0, stream, CB_CHAIN_DELAY_US * 100u);
   if (b.chunked) {
     hipLaunchKernelGGL(chunk_count_kernel, dim3(b.n_waves), dim3(64), 0, stream, b);
     hipLaunchKernelGGL(group_scan_rows_kernel, dim3(b.n_groups), dim3(256), 0, stream, b);
@@ -1226,7 +1241,10 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   const unsigned long long rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
   const unsigned long long by_cap = rows * b.max_regions / b.slice_regions;  // slices of the largest size
   const unsigned long long slices = b.n_tiles + (by_cap > kSliceTargetGroups ? by_cap : kSliceTargetGroups) + 1ull;
-  if (b.two_level) {
+#ifndef CB_GATHER_NARROW_TWO_LEVEL
+#define CB_GATHER_NARROW_TWO_LEVEL 0
+#endif
+  if (b.two_level && CB_GATHER_NARROW_TWO_LEVEL) {
     hipLaunchKernelGGL(bin_gather_accumulate_kernel<kAccThreadsNarrow>, dim3((uint32_t) slices), dim3(kAccThreadsNarrow),
                        CB_GATHER_LDS_PAD, stream, b, hist, w, h);
   } else {

@@ -12,8 +12,9 @@ for l in open(path):
     if l.startswith("{"):
         d = json.loads(l)
         r = d["roofline"]
-        print("%-8s step %.3f ms  draw beside scatter %.3f  alone %.3f  scatter alone %.3f  value %.0f" % (
-            tag, d["ms_per_step"], r["avg_launch_ms"], r["alone_ms"], d.get("roofline_scatter", {}).get("alone_ms", 0), d["value"]))
+        sc = d.get("roofline_scatter", {})
+        print("%-8s step %.3f ms  draw beside scatter %.3f  alone %.3f  scatter alone %.3f  beside the draw %.3f  value %.0f" % (
+            tag, d["ms_per_step"], r["avg_launch_ms"], r["alone_ms"], sc.get("avg_launch_ms", 0), sc.get("pipelined_ms", 0), d["value"]))
 PY
 }
 for k in $(seq $rounds); do
