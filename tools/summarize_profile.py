@@ -21,7 +21,7 @@ os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 KERNELS = ("draw_wave_kernel", "draw_wide_kernel", "bin_region_heads_kernel", "bin_fill_regions_kernel", "bin_slice_table_kernel", "bin_region_sort_kernel",
            "bin_gather_accumulate_kernel", "group_count_kernel", "group_scan_rows_kernel", "group_scan_keys_kernel",
-           "group_scatter_kernel", "chunk_count_kernel", "chunk_list_kernel")
+           "group_scatter_kernel", "chunk_count_kernel", "chunk_list_kernel", "chain_delay_kernel")
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
