@@ -1241,6 +1241,9 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
   const unsigned long long rows = b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles;
   const unsigned long long by_cap = rows * b.max_regions / b.slice_regions;  // slices of the largest size
   const unsigned long long slices = b.n_tiles + (by_cap > kSliceTargetGroups ? by_cap : kSliceTargetGroups) + 1ull;
+  // 1024 threads per workgroup on every canvas.  (Canvases of more than 1024 tiles had 512, for two workgroups per CU
+  // with the GPU to themselves; beside the draw launch there is LDS for ONE 64 KiB tile per CU either way, and a
+  // workgroup of 1024 threads has twice the runs in flight: C4 +3 %, tools/gpu_define_sweep.sh.)
 #ifndef CB_GATHER_NARROW_TWO_LEVEL
 #define CB_GATHER_NARROW_TWO_LEVEL 0
 #endif

@@ -164,7 +164,11 @@ size_t cb_carry_bytes(uint32_t n_threads);
  * histogram with coalesced atomics.  Same dims, n_threads, d_workspace and workspace_bytes as that
  * call.  A no-op for a workspace the draw call could not use.  Precondition: the workspace was last written by
  * a cb_draw_buddhabrot call with these arguments (a call that launches nothing -- no samples, nothing to
- * drain -- leaves an empty stream); flushing a workspace no draw call has touched is undefined. */
+ * drain -- leaves an empty stream); flushing a workspace no draw call has touched is undefined.
+ * Meant to run on ANOTHER stream than the next draw call, beside it (two workspaces, as cb_renderer does): its kernels
+ * fit the CUs beside the two-waves-per-SIMD draw kernel.  The first of them is one wave that sleeps 40 us, so that a
+ * draw launch released by the same event reaches the empty CUs first (otherwise the region
+ * sort cannot be resident beside the draw's waves and runs after them). */
 int cb_flush_scatter(const cb_fractal_dimensions *dims, cb_pixel *d_hist, uint32_t n_threads,
                      void *d_workspace, size_t workspace_bytes, void *stream);
 
