@@ -338,6 +338,13 @@ constexpr uint32_t kFewTilesMax = 256;
 #define CB_SORT_GRID 32768
 #endif
 constexpr uint32_t kSortGrid = CB_SORT_GRID;  // workgroups of the region sort (each takes every kSortGrid-th region)
+// The lean instance takes kRunBatch CONSECUTIVE regions at a time and publishes a tile's run starts in them as ONE
+// 16-byte store: run_start is [tile][region], a region's 1024 run starts lie a row apart, and as 2-byte stores each
+// costs the fabric a sector of its own (C3: 44 MB of table, 1.2 GB written; C4: 87 MB, 2.3 GB).
+#ifndef CB_RUN_BATCH
+#define CB_RUN_BATCH 8
+#endif
+constexpr uint32_t kRunBatch = CB_RUN_BATCH;  // 8 (16-byte stores), or 1: a store of 2 bytes per tile and region
 
 // kPlain: one plane and the plain word row << 16 | col (every render that is not a fused multi-channel one):
 // tile and offset with constant shifts instead of the layout's run-time fields.
@@ -373,7 +380,23 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   // to do (0.25 ms of a steady launch, 0.7 ms of a drain launch's thin stream).  (A grid of just the 512
   // resident workgroups was 12 % slower: the two workgroups of a CU fall into step.)
   const uint32_t n_regions = *b.n_regions;
-  for (uint32_t r = blockIdx.x; r < n_regions; r += gridDim.x) {
+  constexpr uint32_t kBatchRegions = kLean ? kRunBatch : 1u;
+  for (uint32_t r_batch = blockIdx.x * kBatchRegions; r_batch < n_regions; r_batch += gridDim.x * kBatchRegions) {
+  // kLean: this thread's tile's run starts in the regions of the batch, the first one in the lowest half-word (a
+  // region the batch or this instance does not have: 0 -- the general instance, launched after this one, writes its own)
+  uint32_t runs[4] = {0u, 0u, 0u, 0u};
+  const auto push_run = [&](uint32_t v) {
+    runs[0] = __builtin_amdgcn_alignbit(runs[1], runs[0], 16);
+    runs[1] = __builtin_amdgcn_alignbit(runs[2], runs[1], 16);
+    runs[2] = __builtin_amdgcn_alignbit(runs[3], runs[2], 16);
+    runs[3] = __builtin_amdgcn_alignbit(v, runs[3], 16);
+  };
+#pragma unroll 1
+  for (uint32_t r = r_batch; r < r_batch + kBatchRegions; ++r) {
+  if (kLean && r >= n_regions) {
+    push_run(0u);
+    continue;
+  }
   uint32_t n = kChunked ? 0u : b.region_count[r];
   const unsigned long long start = kChunked ? (unsigned long long) r * kRegionEntries : b.region_start[r];
   const uint32_t *src = kChunked ? b.stream : (b.two_level ? b.grouped : b.stream) + start;
@@ -402,7 +425,10 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   // the two-waves-per-SIMD draw kernel its vector instructions are what it costs.
   const bool lean_region = kPlain && n != 0u && (kChunked || (start & 7ull) == 0ull);
   if (!kLean && skip_lean != 0u && lean_region) continue;  // (the lean instance's)
-  if (kLean && !lean_region) continue;
+  if (kLean && !lean_region) {
+    push_run(0u);
+    continue;
+  }
   if constexpr (kLean) {
     // LDS byte addresses as integers (the counters of this lane's replica, less the group's first key; the image), so
     // that an entry's counter is ONE shift-and-add away from its key and the image takes positions as they are
@@ -484,7 +510,11 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
       }
       uint32_t first = sort_exclusive_scan(sum, wave_totals);
       __syncthreads();
-      if (threadIdx.x < nk) b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) (first >> 1);
+      if (kRunBatch == 8u) {
+        push_run(first >> 1);  // (a thread beyond the group's tiles: the region's entries, which nobody reads)
+      } else if (threadIdx.x < nk) {
+        b.run_start[(size_t) threadIdx.x * b.max_regions + r] = (uint16_t) (first >> 1);
+      }
 #pragma unroll
       for (uint32_t k = 0; k < kCntReplicas; ++k) {
         if (has_key) lds[k * kCntStride + threadIdx.x] = image_at + first;
@@ -654,7 +684,12 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
   }
   if (kChunked && threadIdx.x == 0) b.region_count[r] = n;  // from chunks to entries (every region is sorted once)
   }  // (not the lean instance)
-  }  // regions of this workgroup
+  }  // regions of the batch
+  if (kLean && kRunBatch == 8u && threadIdx.x < (b.n_tiles < kGroupTiles ? b.n_tiles : kGroupTiles)) {
+    *reinterpret_cast<uint4 *>(b.run_start + (size_t) threadIdx.x * b.max_regions + r_batch) =
+        make_uint4(runs[0], runs[1], runs[2], runs[3]);
+  }
+  }  // batches of this workgroup
 }
 
 // ---- gather + accumulate ---------------------------------------------------------------------------
@@ -1021,10 +1056,17 @@ Shape shape_of(int w, int h, uint32_t planes) {
 
 // Upper bound on the number of regions for `entries` stream entries: every wave segment (one level) or
 // group (two levels) ends with one partial region.
+// (A multiple of kRunBatch: a row of run_start is written kRunBatch regions at a time, 16 bytes on a 16-byte boundary.)
 uint32_t max_regions_for(const Shape &s, uint32_t n_waves, unsigned long long entries) {
-  if (s.chunked) return (uint32_t) (entries / kRegionEntries) + s.n_groups + 1u;  // entries = chunks * kChunkWords
-  if (s.two_level) return (uint32_t) (entries / kGroupRegionEntries) + s.n_groups + 1u;
-  return (uint32_t) (entries / kRegionEntries) + n_waves + 1u;
+  uint32_t n;
+  if (s.chunked) {
+    n = (uint32_t) (entries / kRegionEntries) + s.n_groups + 1u;  // entries = chunks * kChunkWords
+  } else if (s.two_level) {
+    n = (uint32_t) (entries / kGroupRegionEntries) + s.n_groups + 1u;
+  } else {
+    n = (uint32_t) (entries / kRegionEntries) + n_waves + 1u;
+  }
+  return (n + kRunBatch - 1u) / kRunBatch * kRunBatch;
 }
 
 // Bytes of everything but the per-entry buffers, for a region table of max_regions.
@@ -1218,20 +1260,21 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
 #ifndef CB_GATHER_LDS_PAD  // (likewise for the gather, whose 64 KiB tile is static)
 #define CB_GATHER_LDS_PAD 0
 #endif
-  const auto launch_sort = [&](auto kernel, size_t lds_bytes) -> hipError_t {
+  const auto launch_sort = [&](auto kernel, size_t lds_bytes, uint32_t batch = 1u) -> hipError_t {
     lds_bytes += CB_SORT_LDS_PAD;
     // per call: the attribute belongs to the current device
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_bytes);  // ~74 KiB of the 160 per CU
     if (e != hipSuccess) return e;
-    const uint32_t grid = b.max_regions < kSortGrid ? b.max_regions : kSortGrid;
+    const uint32_t batches = (b.max_regions + batch - 1u) / batch;  // (the lean instance: kRunBatch regions at a time)
+    const uint32_t grid = batches < kSortGrid ? batches : kSortGrid;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(kSortThreads), lds_bytes, stream, b, skip_lean);
     return hipSuccess;
   };
   hipError_t se;
   if (b.chunked) {
 #ifndef CB_NO_LEAN_SORT
-    se = plain ? launch_sort(bin_region_sort_kernel<true, false, true, true>, SortLds<false>::kBytes)
+    se = plain ? launch_sort(bin_region_sort_kernel<true, false, true, true>, SortLds<false>::kBytes, kRunBatch)
 #else
     se = plain ? launch_sort(bin_region_sort_kernel<true, false, true>, SortLds<false>::kBytes)
 #endif
@@ -1239,8 +1282,8 @@ hipError_t launch_binned_scatter(const BinLayout &b, unsigned long long *hist, i
 #ifndef CB_NO_LEAN_SORT
   } else if (plain && !b.two_level && b.tiles_x <= 128u) {  // (columns below 16384: the lean instance's word)
     // the full regions first (lean instance: 10 vector instructions per entry), then the waves' last, partial ones
-    se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes)
-             : launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes);
+    se = few ? launch_sort(bin_region_sort_kernel<true, true, false, true>, SortLds<true>::kBytes, kRunBatch)
+             : launch_sort(bin_region_sort_kernel<true, false, false, true>, SortLds<false>::kBytes, kRunBatch);
     // (a one-level plain stream: every region starts on a 16-byte boundary of its wave's segment -- cap is a multiple
     // of 8 entries -- so the general instance has nothing left)
     if (se == hipSuccess && (b.cap & 7u) != 0u) {
