@@ -1037,19 +1037,28 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"
+#ifdef CB_EXPERIMENT_PACKED24  /* timing only: 3-byte entries, two stores per step (the sort does not read them) */
+#define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 12, %[col]\n\t"
+#define CBW_REPLAY_PLACE "v_add_u32 %[pidx], %[pidx], %[fill]\n\t" "v_mul_u32_u24 %[pidx], 3, %[pidx]\n\t"
+#define CBW_REPLAY_STORE "global_store_short %[pidx], %[e], %[base]\n\t" "global_store_byte_d16_hi %[pidx], %[e], %[base] offset:2\n\t"
+#else
+#define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"
+#define CBW_REPLAY_PLACE "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"
+#define CBW_REPLAY_STORE "global_store_dword %[pidx], %[e], %[base]\n\t"
+#endif
 #define CBW_REPLAY_LOOP                                   \
   CBW_REPLAY_STEP_COMMON                                  \
   "s_and_b64 vcc, vcc, %[hx]\n\t"                         \
   "v_mul_f64 %[a], %[r], %[r]\n\t"                        \
-  "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"            \
+  CBW_REPLAY_WORD                                         \
   "v_mbcnt_lo_u32_b32 %[pidx], vcc_lo, 0\n\t"             \
   "v_fma_f64 %[a], %[i], %[i], %[a]\n\t"                  \
   "v_mbcnt_hi_u32_b32 %[pidx], vcc_hi, %[pidx]\n\t"       \
   "s_bcnt1_i32_b64 %[t], vcc\n\t"                         \
-  "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"       \
+  CBW_REPLAY_PLACE                                        \
   "s_and_b64 %[act], %[act], %[alive]\n\t"                \
   "s_mov_b64 exec, vcc\n\t"                               \
-  "global_store_dword %[pidx], %[e], %[base]\n\t"         \
+  CBW_REPLAY_STORE                                        \
   "s_add_u32 %[fill], %[fill], %[t]\n\t"                  \
   "s_mov_b64 exec, %[act]\n\t"                            \
   "s_cbranch_execz 8f\n\t"              /* (not taken but once) */ \
