@@ -264,12 +264,24 @@ __global__ void __launch_bounds__(256) bin_fill_regions_kernel(BinLayout b) {
 // How many regions one accumulate workgroup gathers from.  A workgroup zeroes and flushes a 64 KiB tile, so it
 // wants many regions; the GPU wants thousands of workgroups, and a canvas of few tiles (the reference's 1000 x
 // 1000 default has 64) would otherwise give a few hundred.  pairs = (tile, region) pairs of the launch.
-constexpr uint32_t kSliceTargetGroups = 12288;
+#ifndef CB_SLICE_TARGET
+#define CB_SLICE_TARGET 12288
+#endif
+#ifndef CB_SLICE_TARGET_TWO_LEVEL
+#define CB_SLICE_TARGET_TWO_LEVEL 6144
+#endif
+constexpr uint32_t kSliceTargetGroups = CB_SLICE_TARGET;
+// ... on a canvas of more than 1024 tiles the tiles alone are thousands of workgroups, a tile sees few entries per
+// slice, and what a further slice of a tile costs is a 64 KiB tile zeroed, scanned and flushed once more (C4: 24649
+// tiles; 9.95 -> 9.45 ms per step with half the slices beyond one per tile, and no different with fewer still)
+constexpr uint32_t kSliceTargetGroupsTwoLevel = CB_SLICE_TARGET_TWO_LEVEL;
+static_assert(kSliceTargetGroupsTwoLevel <= kSliceTargetGroups, "the grid of the gather is sized by the larger one");
 constexpr uint32_t kSliceRegionsMin = 512;  // one run per lane: fewer leave waves of the workgroup without work
 constexpr uint32_t kSliceEntriesMin = 32768;  // ... and a workgroup should find a few entries per pixel of its tile
 __device__ __forceinline__ uint32_t slice_regions_for(const BinLayout &b, unsigned long long pairs,
                                                       unsigned long long entries) {
-  unsigned long long s = (pairs + kSliceTargetGroups - 1u) / kSliceTargetGroups;
+  const unsigned long long target = b.two_level ? kSliceTargetGroupsTwoLevel : kSliceTargetGroups;
+  unsigned long long s = (pairs + target - 1u) / target;
   if (s < kSliceRegionsMin) s = kSliceRegionsMin;
   // a thin stream (the launch that only drains: a partial region per wave): fewer, longer slices
   const unsigned long long by_entries = entries ? (kSliceEntriesMin * pairs + entries - 1u) / entries : b.slice_regions;
