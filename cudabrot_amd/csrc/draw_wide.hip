@@ -1037,6 +1037,26 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
   "v_cvt_i32_f64 %[col], %[fx]\n\t"                       \
   "v_fma_f64 %[r], %[a], 0.5, %[cr]\n\t"                  \
   "v_cvt_i32_f64 %[row], %[fy]\n\t"
+// Cache policy of the stream's stores (gfx942+ bits: sc0, sc1, nt), as text behind the instruction.  The stream is
+// written once and read once, a launch later.
+#ifndef CB_STREAM_STORE_POLICY_ID  // (a number, so that a sweep can pass it through make: tools/gpu_define_sweep.sh)
+#define CB_STREAM_STORE_POLICY_ID 0
+#endif
+#if CB_STREAM_STORE_POLICY_ID == 0
+#define CB_STREAM_STORE_POLICY ""
+#elif CB_STREAM_STORE_POLICY_ID == 1
+#define CB_STREAM_STORE_POLICY " nt"
+#elif CB_STREAM_STORE_POLICY_ID == 2
+#define CB_STREAM_STORE_POLICY " sc1"
+#elif CB_STREAM_STORE_POLICY_ID == 3
+#define CB_STREAM_STORE_POLICY " sc0 sc1"
+#elif CB_STREAM_STORE_POLICY_ID == 4
+#define CB_STREAM_STORE_POLICY " sc0 sc1 nt"
+#elif CB_STREAM_STORE_POLICY_ID == 5
+#define CB_STREAM_STORE_POLICY " sc0"
+#elif CB_STREAM_STORE_POLICY_ID == 6
+#define CB_STREAM_STORE_POLICY " sc1 nt"
+#endif
 #ifdef CB_EXPERIMENT_PACKED24  /* timing only: 3-byte entries, two stores per step (the sort does not read them) */
 #define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 12, %[col]\n\t"
 #define CBW_REPLAY_PLACE "v_add_u32 %[pidx], %[pidx], %[fill]\n\t" "v_mul_u32_u24 %[pidx], 3, %[pidx]\n\t"
@@ -1044,7 +1064,7 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
 #else
 #define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"
 #define CBW_REPLAY_PLACE "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"
-#define CBW_REPLAY_STORE "global_store_dword %[pidx], %[e], %[base]\n\t"
+#define CBW_REPLAY_STORE "global_store_dword %[pidx], %[e], %[base]" CB_STREAM_STORE_POLICY "\n\t"
 #endif
 #define CBW_REPLAY_LOOP                                   \
   CBW_REPLAY_STEP_COMMON                                  \
@@ -1114,7 +1134,7 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
   "s_andn2_b64 %[over], exec, vcc\n\t"                    \
   "s_mov_b64 exec, vcc\n\t"                               \
   "v_lshlrev_b32 %[pos], 2, %[pos]\n\t"                   \
-  "global_store_dword %[pos], %[e], %[base]\n\t"          \
+  "global_store_dword %[pos], %[e], %[base]" CB_STREAM_STORE_POLICY "\n\t" \
   "s_cmp_lg_u64 %[over], 0\n\t"                           \
   "s_cbranch_scc1 8f\n\t"               /* (the step is complete: it counts) */ \
   "s_mov_b64 exec, %[act]\n\t"                            \

@@ -358,6 +358,20 @@ constexpr uint32_t kSortGrid = CB_SORT_GRID;  // workgroups of the region sort (
 #endif
 constexpr uint32_t kRunBatch = CB_RUN_BATCH;  // 8 (16-byte stores), or 1: a store of 2 bytes per tile and region
 
+// 16 bytes of the stream, which the sort reads once (CB_SORT_NT_LOADS: as a non-temporal load)
+#ifndef CB_SORT_NT_LOADS
+#define CB_SORT_NT_LOADS 0
+#endif
+__device__ __forceinline__ uint4 stream_load16(const uint4 *p) {
+#if CB_SORT_NT_LOADS
+  typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+  const U32x4 v = __builtin_nontemporal_load(reinterpret_cast<const U32x4 *>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+
 // kPlain: one plane and the plain word row << 16 | col (every render that is not a fused multi-channel one):
 // tile and offset with constant shifts instead of the layout's run-time fields.
 template <bool kPlain>
@@ -479,9 +493,9 @@ __global__ void __launch_bounds__(kSortThreads, 8) bin_region_sort_kernel(BinLay
         if (kChunked) {  // (a chunk the region does not have: {0, 0} -- the start of the stream, no words)
           const uint2 cd = chunks[4u * (part * kBatch + j) + my_chunk];
           words_g[j] = cd.y;
-          v[j] = src4[(size_t) (cd.x >> 2) + in_chunk];
+          v[j] = stream_load16(&src4[(size_t) (cd.x >> 2) + in_chunk]);
         } else {
-          v[j] = src4[kMasked ? (i4 < last4 ? i4 : last4) : i4];
+          v[j] = stream_load16(&src4[kMasked ? (i4 < last4 ? i4 : last4) : i4]);
         }
       }
 #pragma unroll
