@@ -494,7 +494,9 @@ def main():
             if name == args.config:
                 continue
             try:
-                other_configs[name] = other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread)
+                # (as many steps as the headline's timed region: a leg's drain launch weighs what the headline's does)
+                other_configs[name] = other_config_leg(cb, torch, np, dev, name, threads, samples_per_thread,
+                                                       steps=max(4, min(args.steps, 50)))
             except Exception as e:   # a leg that fails says so in the line; it never takes the headline down
                 other_configs[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
