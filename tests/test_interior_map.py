@@ -124,7 +124,7 @@ def test_a_stratum_of_every_depth_is_proven_again(tool, tmp_path):
     depth each proof needed (cudabrot_amd/interior_map.depths.gz: one byte per marked cell, none unknown, none beyond
     the kept budget of ten levels of quarters -- nine for the map as round 3 made it, ten for the 2185 cells round 4's
     anytime run over its rim added).  Here, on every CPU run: the notes belong to this map, and a random
-    stratum of EVERY depth -- 60 cells each of depth 1..10, the deep ones being where a bit set by accident would have to
+    stratum of EVERY depth -- 40 cells each of depth 1..10, the deep ones being where a bit set by accident would have to
     hide -- plus 2000 random cells are proven again by the prover AT THE DEPTH NOTED (a cell that is not interior cannot
     be proven at any depth; one that needs another depth than noted says the notes are not this tool's)."""
     raw = gzip.open(KEPT, "rb").read()
@@ -139,8 +139,8 @@ def test_a_stratum_of_every_depth_is_proven_again(tool, tmp_path):
     assert int(depths.max()) <= 10, "a marked cell without a proof within the kept budget"
     side = str(tmp_path / "depths.bin")
     open(side, "wb").write(notes)
-    # 60 cells of EVERY depth 1..10 (a stratum each, drawn at random) and 2000 random others (two thirds of them depth 0)
-    out = run(tool, "verify", "12", kept, "10", side, "2000", "0", "2026", "60")
+    # 40 cells of EVERY depth 1..10 (a stratum each, drawn at random) and 2000 random others (two thirds of them depth 0)
+    out = run(tool, "verify", "12", kept, "10", side, "2000", "0", "2026", "40")
     m = re.search(r"proved (\d+) cells, (\d+) NOT proven, (\d+) with another depth than noted", out)
     assert m and int(m.group(2)) == 0 and int(m.group(3)) == 0, out
-    assert int(m.group(1)) >= 10 * 60 + 1500, out
+    assert int(m.group(1)) >= 10 * 40 + 1500, out
