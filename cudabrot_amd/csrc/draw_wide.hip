@@ -1061,6 +1061,10 @@ __device__ __forceinline__ void long_retire4(const Orbit (&o)[kSlots], double (&
 #define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 12, %[col]\n\t"
 #define CBW_REPLAY_PLACE "v_add_u32 %[pidx], %[pidx], %[fill]\n\t" "v_mul_u32_u24 %[pidx], 3, %[pidx]\n\t"
 #define CBW_REPLAY_STORE "global_store_short %[pidx], %[e], %[base]\n\t" "global_store_byte_d16_hi %[pidx], %[e], %[base] offset:2\n\t"
+#elif defined(CB_EXPERIMENT_NO_STREAM_STORE)  /* timing only: the replay without its store (one-level streams) */
+#define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"
+#define CBW_REPLAY_PLACE "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"
+#define CBW_REPLAY_STORE ""
 #else
 #define CBW_REPLAY_WORD "v_lshl_or_b32 %[e], %[row], 16, %[col]\n\t"
 #define CBW_REPLAY_PLACE "v_add_lshl_u32 %[pidx], %[pidx], %[fill], 2\n\t"

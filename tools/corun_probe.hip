@@ -109,6 +109,16 @@ __global__ void __launch_bounds__(1024, 8) neighbour_kernel(unsigned long long t
   if ((threadIdx.x & 63u) == 0u) atomicAdd(turns_out, turns);
 }
 
+// One wave that sleeps beside the two and reads both clocks: the shader clock's frequency while they run.
+__global__ void __launch_bounds__(64) clock_sampler_kernel(unsigned long long ticks, unsigned long long *out) {
+  const unsigned long long w0 = wall_clock64(), c0 = clock64();
+  for (uint32_t turn = 0; turn < (1u << 22) && wall_clock64() - w0 < ticks; ++turn) __builtin_amdgcn_s_sleep(64);
+  if (threadIdx.x == 0) {
+    out[0] = wall_clock64() - w0;  // 100 MHz
+    out[1] = clock64() - c0;       // shader clock
+  }
+}
+
 int main(int argc, char **argv) {
   const uint32_t sleep = argc > 1 ? (uint32_t) atoi(argv[1]) : 0u;
   cb_fractal_dimensions dims;
@@ -118,9 +128,10 @@ int main(int argc, char **argv) {
   if (cb_recompute_pixel_deltas(&dims, &msg) != 1) { fprintf(stderr, "canvas: %s\n", msg ? msg : "?"); return 1; }
   cb_iteration_control it = {20000, 20};
   const uint32_t threads = 262144, spt = 50 * 64;
-  hipStream_t sa, sb;
+  hipStream_t sa, sb, sc;
   CHECK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
   CHECK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  CHECK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
   void *states, *ws, *carry, *src;
   cb_pixel *hist;
   cb_counters *counters;
@@ -135,6 +146,8 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc(&counters, sizeof(cb_counters)));
   CHECK(hipMemset(counters, 0, sizeof(cb_counters)));
   CHECK(hipMalloc(&turns, 16));
+  unsigned long long *clocks;
+  CHECK(hipMalloc(&clocks, 16));
   const uint32_t src_mask = (1u << 26) - 1u;  // 2^26 x 16 B = 1 GiB
   CHECK(hipMalloc(&src, ((size_t) src_mask + 1) * 16));
   CHECK(hipMemset(src, 1, ((size_t) src_mask + 1) * 16));
@@ -154,7 +167,7 @@ int main(int argc, char **argv) {
          sleep ? "sleeping 127 x 64 cycles after every 64 instructions" : "no pauses");
   double alone = 0;
   for (int kind = 0; kind < kKinds; ++kind) {
-    double ms_sum = 0, rate_sum = 0;
+    double ms_sum = 0, rate_sum = 0, ghz_sum = 0;
     const int reps = 3;
     double life_ms = alone > 0 ? alone : 6.0;
     for (int rep = -2; rep < reps; ++rep) {  // (two settling turns: the neighbour's life follows the draw's time)
@@ -166,6 +179,7 @@ int main(int argc, char **argv) {
       CHECK(hipEventRecord(e1, sa));
       // (the draw launch first: its waves take the low registers of every SIMD, as in the product's pipeline)
       for (volatile int spin = 0; spin < 300000; ++spin) {}
+      hipLaunchKernelGGL(clock_sampler_kernel, dim3(1), dim3(64), 0, sc, (unsigned long long) (life_ms * 0.8e5), clocks);
       const size_t lds_bytes = 65536;
 #define LAUNCH(K) hipLaunchKernelGGL(neighbour_kernel<K>, dim3(256), dim3(1024), lds_bytes, sb, ticks, turns, (const uint4 *) src, src_mask, sleep)
       switch (kind) {
@@ -191,8 +205,11 @@ int main(int argc, char **argv) {
       CHECK(hipMemcpy(h, turns, 16, hipMemcpyDeviceToHost));
       flush();
       CHECK(hipDeviceSynchronize());
+      unsigned long long ck[2];
+      CHECK(hipMemcpy(ck, clocks, 16, hipMemcpyDeviceToHost));
       life_ms = ms;
       if (rep < 0) continue;
+      ghz_sum += ck[0] ? (double) ck[1] / (double) ck[0] * 0.1 : 0.0;
       ms_sum += ms;
       rate_sum += (double) h[0] * (kind == kVmemLoadSlow ? kBody / 8 : kBody) / ((double) ticks / 1e5);  // wave-instructions per ms, all waves together
     }
@@ -200,8 +217,8 @@ int main(int argc, char **argv) {
     if (kind == kNone) alone = ms;
     // wave-instructions the neighbour issued WHILE the draw ran, and what each 10^9 of them cost the draw
     const double beside = rate * ms;
-    printf("%-28s draw %.3f ms (+%.3f)  neighbour %6.1f M wave-instructions per ms  draw's loss per 10^9 of them: %.2f ms\n",
-           kNames[kind], ms, ms - alone, rate / 1e6, beside > 0 ? (ms - alone) / (beside / 1e9) : 0.0);
+    printf("%-28s draw %.3f ms (+%.3f)  shader clock %.2f GHz  neighbour %6.1f M wave-instructions per ms  draw's loss per 10^9 of them: %.2f ms\n",
+           kNames[kind], ms, ms - alone, ghz_sum / reps, rate / 1e6, beside > 0 ? (ms - alone) / (beside / 1e9) : 0.0);
   }
   return 0;
 }
