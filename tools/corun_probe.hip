@@ -13,10 +13,11 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 #define CB(x) do { int rc_ = (x); if (rc_ != 0) { fprintf(stderr, "%s: %d\n", #x, rc_); exit(1); } } while (0)
 
-enum Kind { kNone = 0, kValu, kValuDep, kSalu, kLdsAdd, kLdsAddConflict, kLdsRtn, kVmemLoad, kBranch, kSleep, kVmemL2, kVmemL1, kVmemStore, kVmemLoadSlow, kKinds };
+enum Kind { kNone = 0, kValu, kValuDep, kSalu, kLdsAdd, kLdsAddConflict, kLdsRtn, kVmemLoad, kBranch, kSleep, kVmemL2, kVmemL1, kVmemStore, kVmemLoadSlow, kF64Full, kF64Quarter, kF64Zero, kKinds };
 static const char *kNames[kKinds] = {"none", "valu (4 chains)", "valu (1 chain)", "salu", "ds_add (no conflicts)",
                                      "ds_add (random banks)", "ds_add_rtn + wait", "16-byte loads + wait", "taken branches", "s_sleep only",
-                                     "... from 4 MiB (L2 hits)", "... from 16 KiB (L1 hits)", "16-byte stores (1 GiB)", "16-byte loads, 1 in flight"};
+                                     "... from 4 MiB (L2 hits)", "... from 16 KiB (L1 hits)", "16-byte stores (1 GiB)", "16-byte loads, 1 in flight",
+                                     "fp64 fma, 4 chains, 64 lanes", "... 16 of 64 lanes (EXEC)", "... 64 lanes, operands 0"};
 
 // One turn = kBody instructions of the kind.  duty: after each turn the wave sleeps `sleep` x 64 cycles.
 constexpr int kBody = 64;
@@ -41,6 +42,17 @@ __global__ void __launch_bounds__(1024, 8) neighbour_kernel(unsigned long long t
         asm volatile("v_fma_f32 %0, %0, %0, %0\n\tv_fma_f32 %1, %1, %1, %1\n\tv_fma_f32 %2, %2, %2, %2\n\tv_fma_f32 %3, %3, %3, %3"
                      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
       }
+    } else if (KIND == kF64Full || KIND == kF64Quarter || KIND == kF64Zero) {
+      // fp64 fma chains with all lanes, with a quarter of them (EXEC), and with all lanes on operands that never change
+      double da = KIND == kF64Zero ? 0.0 : (double) a, db = KIND == kF64Zero ? 0.0 : 1.25, dc = KIND == kF64Zero ? 0.0 : 2.5, dd = KIND == kF64Zero ? 0.0 : 3.75;
+      if (KIND != kF64Quarter || (threadIdx.x & 63u) < 16u) {
+#pragma unroll
+        for (int k = 0; k < kBody / 4; ++k) {
+          asm volatile("v_fma_f64 %0, %0, %0, %0\n\tv_fma_f64 %1, %1, %1, %1\n\tv_fma_f64 %2, %2, %2, %2\n\tv_fma_f64 %3, %3, %3, %3"
+                       : "+v"(da), "+v"(db), "+v"(dc), "+v"(dd));
+        }
+      }
+      a += (float) (da + db + dc + dd);
     } else if (KIND == kValuDep) {
 #pragma unroll
       for (int k = 0; k < kBody; ++k) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(a));
@@ -197,6 +209,9 @@ int main(int argc, char **argv) {
         case kVmemL1: LAUNCH(kVmemL1); break;
         case kVmemStore: LAUNCH(kVmemStore); break;
         case kVmemLoadSlow: LAUNCH(kVmemLoadSlow); break;
+        case kF64Full: LAUNCH(kF64Full); break;
+        case kF64Quarter: LAUNCH(kF64Quarter); break;
+        case kF64Zero: LAUNCH(kF64Zero); break;
       }
       CHECK(hipDeviceSynchronize());
       float ms = 0;
